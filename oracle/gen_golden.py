@@ -1,0 +1,168 @@
+"""TEST INFRASTRUCTURE — generates tests/golden/*.npz by running the *reference* code.
+
+Run in the build container only (needs /root/reference):  python -m oracle.gen_golden
+Each fixture stores inputs + reference outputs (never reference source).  Weights
+are not stored: they are re-derived from parameter names by
+perceptor_amd.utils.synth (seed 0), identically here and on the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+warnings.filterwarnings("ignore")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import _refimport as R  # noqa: E402
+from perceptor_amd.utils.synth import seeded_noise, synth_like  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"),
+                        **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    print("wrote", name, {k: tuple(np.asarray(v).shape) for k, v in arrs.items()})
+
+
+def moments(y):
+    f = y.flatten(1).double()
+    return torch.stack([f.mean(1), f.std(1), f.norm(dim=1)], dim=1).float()
+
+
+def gen_sampling():
+    gd = R.ref("models.guided_diffusion.guided_diffusion")
+    su = R.ref("models.guided_diffusion.script_util")
+    P = R.ref("models.guided_diffusion.predictions").Predictions
+    vd = R.ref("models.velocity_diffusion.velocity_diffusion")
+    VP = R.ref("models.velocity_diffusion.predictions").Predictions
+    # wrapper built by hand: the real __init__ downloads a checkpoint (guided_diffusion.py:25-36)
+    g = gd.GuidedDiffusion.__new__(gd.GuidedDiffusion)
+    torch.nn.Module.__init__(g)
+    diffusion = su.create_gaussian_diffusion(steps=1000, learn_sigma=True, noise_schedule="linear")
+    g.schedule_alphas = torch.nn.Parameter(torch.from_numpy(diffusion.alphas_cumprod).sqrt().float(), requires_grad=False)
+    g.schedule_sigmas = torch.nn.Parameter((1 - torch.from_numpy(diffusion.alphas_cumprod)).sqrt().float(), requires_grad=False)
+    out = dict(alphas=g.schedule_alphas.data, sigmas=g.schedule_sigmas.data,
+               idx_50_r3=g.schedule_indices(n_steps=50, rho=3.0), idx_50_r7=g.schedule_indices(n_steps=50, rho=7.0),
+               idx_250_r7=g.schedule_indices(n_steps=250, rho=7.0),
+               idx_20_400=g.schedule_indices(n_steps=20, from_index=400, to_index=0),
+               ts_50=vd.VelocityDiffusion.schedule_ts(n_steps=50), ts_500=vd.VelocityDiffusion.schedule_ts())
+    img = seeded_noise((2, 3, 16, 16), 21) * 0.3 + 0.5
+    eps = seeded_noise((2, 3, 16, 16), 22)
+    grad = seeded_noise((2, 3, 16, 16), 23) * 2e-6
+    fi, ti = torch.tensor([900, 37]), torch.tensor([850, 0])
+    p = P(from_diffused_images=img, from_indices=fi, predicted_noise=eps,
+          schedule_alphas=g.schedule_alphas.data, schedule_sigmas=g.schedule_sigmas.data)
+    pg = p.guided(grad, guidance_scale=0.5, clamp_value=1e-6)
+    out.update(img=img, eps=eps, grad=grad, fi=fi, ti=ti, eps_denoised=p.denoised_images, eps_step=p.step(ti),
+               eps_guided=pg.predicted_noise, eps_guided_step=pg.step(ti),
+               eps_forced=p.forced_denoised_images(p.denoised_images.clamp(0, 1)).predicted_noise,
+               # reference defect: dynamic_threshold broadcasts an [N] threshold against NCHW, so it only
+               # runs for N == 1 (predictions.py:156-172) -> fixture uses the first sample alone
+               eps_dynthr=P(from_diffused_images=img[:1], from_indices=fi[:1], predicted_noise=eps[:1] * 3,
+                            schedule_alphas=g.schedule_alphas.data, schedule_sigmas=g.schedule_sigmas.data
+                            ).dynamic_threshold(0.95).predicted_noise,
+               eps_reverse=P(from_diffused_images=img, from_indices=ti, predicted_noise=eps,
+                             schedule_alphas=g.schedule_alphas.data, schedule_sigmas=g.schedule_sigmas.data).reverse_step(fi))
+    ft, tt = torch.tensor([0.9, 0.05]), torch.tensor([0.8, 0.01])
+    v = VP(from_diffused_images=img, from_ts=ft, velocities=eps)
+    vg = v.guided(grad, guidance_scale=0.5, clamp_value=1e-6)
+    out.update(ft=ft, tt=tt, v_denoised=v.denoised_images, v_eps=v.predicted_noise, v_step=v.step(tt),
+               v_guided=vg.velocities, v_guided_step=vg.step(tt),
+               v_forced=v.forced_denoised_images(v.denoised_images.clamp(0, 1)).velocities,
+               v_forced_eps=v.forced_predicted_noise(eps * 0.5).velocities,
+               v_static=v.static_threshold().velocities,
+               v_dynthr=VP(from_diffused_images=img[:1], from_ts=ft[:1], velocities=eps[:1] * 3).dynamic_threshold(0.95).velocities)
+    save("sampling", **out)
+
+
+ADM_TINY = {
+    "a": dict(image_size=64, num_channels=32, num_res_blocks=1, channel_mult="1,2,2", learn_sigma=True,
+              attention_resolutions="32,16", num_head_channels=16, use_scale_shift_norm=True, resblock_updown=True),
+    "b": dict(image_size=64, num_channels=32, num_res_blocks=2, channel_mult="1,2", learn_sigma=True,
+              attention_resolutions="32", num_heads=2, use_scale_shift_norm=False, resblock_updown=False,
+              use_new_attention_order=True),
+}
+
+
+def gen_adm():
+    su = R.ref("models.guided_diffusion.script_util")
+    cm = R.ref("models.guided_diffusion.create_models")
+    for tag, kw in ADM_TINY.items():
+        m = su.create_model(**kw).eval()
+        m.load_state_dict(synth_like(m.state_dict(), 0))
+        x = seeded_noise((2, 3, 64, 64), 31)
+        t = torch.tensor([10, 500])
+        with torch.no_grad():
+            y = m(x, t)
+        save(f"adm_tiny_{tag}", x=x, t=t, y=y)
+    for name, ctor, res in (("standard", cm.create_openimages_model, 128), ("pixelart", cm.create_pixelart_model, 64)):
+        m, _ = ctor()
+        m.convert_to_fp32()
+        m.dtype = torch.float32          # fp32 oracle: the torso's fp16 cast is a GPU-side precision choice
+        m.eval()
+        m.load_state_dict(synth_like(m.state_dict(), 0))
+        x = seeded_noise((1, 3, res, res), 32)
+        t = torch.tensor([333])
+        with torch.no_grad():
+            y = m(x, t)
+        save(f"adm_{name}_{res}", x=x, t=t, y_sub=y[:, :, ::4, ::4].contiguous(), y_mom=moments(y))
+
+
+def gen_vdiff():
+    y2 = R.ref("models.velocity_diffusion.yfcc_2")
+    cc = R.ref("models.velocity_diffusion.cc12m_1")
+    m = y2.YFCC2Model().eval()
+    m.load_state_dict(synth_like(m.state_dict(), 0))
+    x = seeded_noise((1, 3, 128, 128), 41)
+    t = torch.tensor([0.3])
+    with torch.no_grad():
+        y = m(x, t)
+    save("vdiff_yfcc_2_128", x=x, t=t, y_sub=y[:, :, ::4, ::4].contiguous(), y_mom=moments(y))
+    del m
+    m = cc.CC12M1Model().eval()
+    m.load_state_dict(synth_like(m.state_dict(), 0))
+    x = seeded_noise((1, 3, 64, 64), 42)
+    t = torch.tensor([0.7])
+    ce = seeded_noise((1, 512), 43)
+    with torch.no_grad():
+        y = m(x, t, ce)
+    save("vdiff_cc12m_1_64", x=x, t=t, clip_embed=ce, y_sub=y[:, :, ::2, ::2].contiguous(), y_mom=moments(y))
+
+
+def gen_clip():
+    rz = R.ref("transforms.resize.resize_right")
+    ru = R.ref("models.ruclip.model")
+    out = {}
+    for tag, shape, target in (("512_224", (1, 3, 512, 512), (224, 224)), ("256_224", (1, 3, 256, 256), (224, 224)),
+                               ("128_224", (1, 3, 128, 128), (224, 224)), ("96x160_64", (1, 3, 96, 160), (64, 64))):
+        img = seeded_noise(shape, 51) * 0.25 + 0.5
+        out["rz_" + tag] = rz.resize(img, out_shape=target)[:, :, ::3, ::3].contiguous()
+    save("clip_resize", **out)
+    from oracle.clip_vit import CLIP_MEAN, CLIP_STD, VIT_CONFIGS
+    for tag, size, n in (("tiny", 48, 2), ("tiny-odd", 40, 2), ("ViT-B-32", 256, 2)):
+        res, patch, width, layers, heads, odim = VIT_CONFIGS[tag]
+        m = ru.VisionTransformer(res, patch, width, layers, heads, odim).eval()
+        m.load_state_dict(synth_like(m.state_dict(), 0))
+        img = (seeded_noise((n, 3, size, size), 52) * 0.25 + 0.5).requires_grad_(True)
+        mean = torch.tensor(CLIP_MEAN)[None, :, None, None]
+        std = torch.tensor(CLIP_STD)[None, :, None, None]
+        probe = seeded_noise((n, odim), 53)
+        e = m((rz.resize(img, out_shape=(res, res)) - mean) / std)   # QuickGELU tower (ruclip/model.py:20-23)
+        en = torch.nn.functional.normalize(e)
+        (g,) = torch.autograd.grad((en * probe).sum(), img)
+        save(f"clip_vit_{tag}", img=img.detach(), probe=probe, emb=e.detach(), emb_n=en.detach(),
+             grad_sub=g[:, :, ::4, ::4].contiguous(), grad_mom=moments(g))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["sampling", "adm", "vdiff", "clip"]
+    torch.manual_seed(0)
+    for w in which:
+        globals()["gen_" + w]()

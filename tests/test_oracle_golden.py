@@ -1,0 +1,117 @@
+"""CPU: pin the oracle (oracle/*.py) against golden vectors produced by the reference code.
+
+Fixtures come from oracle/gen_golden.py (reference modules imported in the build
+container).  Tolerances: same fp32 ops in a different association order -> 1e-5
+relative to the output scale unless stated.
+"""
+import pytest
+import torch
+
+from conftest import golden
+from oracle import adm_unet, clip_vit, sampling, vdiff
+from perceptor_amd.utils.synth import synth_state_dict
+
+
+def _close(a, b, tol):
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a.double() - b.double()).abs().max())
+    assert err <= tol * scale, f"max abs err {err:.3e} > {tol * scale:.3e}"
+
+
+def test_schedules_and_tables():
+    g = golden("sampling")
+    a, s = sampling.gd_tables()
+    assert torch.equal(a, g["alphas"]) and torch.equal(s, g["sigmas"])
+    assert torch.equal(sampling.schedule_indices(a, s, 50, rho=3.0), g["idx_50_r3"])
+    assert torch.equal(sampling.schedule_indices(a, s, 50, rho=7.0), g["idx_50_r7"])
+    assert torch.equal(sampling.schedule_indices(a, s, 250, rho=7.0), g["idx_250_r7"])
+    assert torch.equal(sampling.schedule_indices(a, s, 20, from_index=400), g["idx_20_400"])
+    assert g["idx_50_r3"][0].tolist() == [994, 988] and g["idx_50_r3"][-1].tolist() == [6, 0]
+    _close(sampling.schedule_ts(50), g["ts_50"], 1e-6)
+    _close(sampling.schedule_ts(500), g["ts_500"], 1e-6)
+    with pytest.raises(ValueError):
+        sampling.schedule_indices(a, s, 10, from_index=0, to_index=5)
+
+
+def test_predictions_algebra():
+    g = golden("sampling")
+    a, s = g["alphas"], g["sigmas"]
+    af, sf, at, st = a[g["fi"]], s[g["fi"]], a[g["ti"]], s[g["ti"]]
+    img, eps, grad = g["img"], g["eps"], g["grad"]
+    _close((sampling.eps_denoised_xs(img, eps, af, sf) + 1) / 2, g["eps_denoised"], 1e-6)
+    _close(sampling.eps_step(img, eps, af, sf, at, st), g["eps_step"], 1e-6)
+    eg = sampling.guided(eps, grad, sf)
+    _close(eg, g["eps_guided"], 1e-6)
+    _close(sampling.eps_step(img, eg, af, sf, at, st), g["eps_guided_step"], 1e-6)
+    den = ((sampling.eps_denoised_xs(img, eps, af, sf) + 1) / 2).clamp(0, 1)
+    _close(sampling.eps_forced_denoised_images(img, den, af, sf), g["eps_forced"], 1e-6)
+    ft, tt = g["ft"], g["tt"]
+    _close((sampling.v_denoised_xs(img, eps, ft) + 1) / 2, g["v_denoised"], 1e-6)
+    _close(sampling.v_predicted_noise(img, eps, ft), g["v_eps"], 1e-6)
+    _close(sampling.v_step(img, eps, ft, tt), g["v_step"], 1e-6)
+    vg = sampling.guided(eps, grad, sampling.t_to_alpha_sigma(ft)[1])
+    _close(vg, g["v_guided"], 1e-6)
+    _close(sampling.v_step(img, vg, ft, tt), g["v_guided_step"], 1e-6)
+
+
+@pytest.mark.parametrize("tag,cfg", [
+    ("a", adm_unet.AdmConfig(64, 32, 1, (1, 2, 2), (2, 4), num_head_channels=16, use_scale_shift_norm=True, resblock_updown=True)),
+    ("b", adm_unet.AdmConfig(64, 32, 2, (1, 2), (2,), num_heads=2, use_new_attention_order=True)),
+])
+def test_adm_tiny(tag, cfg):
+    g = golden(f"adm_tiny_{tag}")
+    sd = synth_state_dict(adm_unet.state_dict_shapes(cfg), 0)
+    _close(adm_unet.adm_unet_forward(sd, cfg, g["x"], g["t"]), g["y"], 1e-5)
+
+
+def test_adm_pixelart_full_64():
+    g = golden("adm_pixelart_64")
+    cfg = adm_unet.pixelart_config()
+    sd = synth_state_dict(adm_unet.state_dict_shapes(cfg), 0)
+    y = adm_unet.adm_unet_forward(sd, cfg, g["x"], g["t"])
+    _close(y[:, :, ::4, ::4], g["y_sub"], 1e-5)
+
+
+def test_adm_standard_full_128():
+    g = golden("adm_standard_128")
+    cfg = adm_unet.openimages_config()
+    shapes = adm_unet.state_dict_shapes(cfg)
+    assert len(shapes) == 644  # GD-standard state dict has 644 tensors
+    sd = synth_state_dict(shapes, 0)
+    y = adm_unet.adm_unet_forward(sd, cfg, g["x"], g["t"])
+    _close(y[:, :, ::4, ::4], g["y_sub"], 1e-5)
+    f = y.flatten(1).double()
+    _close(torch.stack([f.mean(1), f.std(1), f.norm(dim=1)], 1).float(), g["y_mom"], 1e-5)
+
+
+def test_resize_matches_reference():
+    g = golden("clip_resize")
+    from perceptor_amd.utils.synth import seeded_noise
+    for tag, shape, target in (("512_224", (1, 3, 512, 512), (224, 224)), ("256_224", (1, 3, 256, 256), (224, 224)),
+                               ("128_224", (1, 3, 128, 128), (224, 224)), ("96x160_64", (1, 3, 96, 160), (64, 64))):
+        img = seeded_noise(shape, 51) * 0.25 + 0.5
+        _close(clip_vit.resize(img, target)[:, :, ::3, ::3], g["rz_" + tag], 2e-5)  # dense-matrix vs 14-tap gather: fp32 summation order
+
+
+@pytest.mark.parametrize("tag", ["tiny", "tiny-odd", "ViT-B-32"])
+def test_vit_embedding_and_image_gradient(tag):
+    g = golden(f"clip_vit_{tag}")
+    cfg = clip_vit.VIT_CONFIGS[tag]
+    sd = synth_state_dict(clip_vit.vit_state_dict_shapes(cfg), 0)
+    img = g["img"].clone().requires_grad_(True)
+    e = clip_vit.encode_images(sd, cfg, img, quick_gelu=True, normalize=False)
+    _close(e.detach(), g["emb"], 2e-5)
+    en = torch.nn.functional.normalize(e)
+    _close(en.detach(), g["emb_n"], 2e-5)
+    (gr,) = torch.autograd.grad((en * g["probe"]).sum(), img)
+    scale = float(g["grad_sub"].abs().max())
+    assert float((gr[:, :, ::4, ::4] - g["grad_sub"]).abs().max()) <= 2e-4 * scale
+
+
+def test_spherical_loss_known_values():
+    # identical unit vectors -> 0; orthogonal -> 2*asin(sqrt(2)/2)^2 = pi^2/8; antipodal -> pi^2/2
+    e = torch.eye(4)[:2]
+    t = torch.stack([e[0], e[1], -e[0]])
+    d = (e[:, None] - t[None]).norm(dim=2).div(2).arcsin().square().mul(2)
+    assert torch.allclose(d[0], torch.tensor([0.0, torch.pi**2 / 8, torch.pi**2 / 2]), atol=1e-5)
+    assert torch.allclose(clip_vit.spherical_loss(e, t, torch.ones(3)), d.mean(), atol=1e-6)
