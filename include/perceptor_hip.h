@@ -1,0 +1,148 @@
+/* perceptor_hip.h — C ABI of libperceptor_hip.so (gfx950 / MI355X).
+ *
+ * perceptor itself has no FFI: its hot path is stock PyTorch ops dispatched from
+ * Python.  Each entry point below replaces the PyTorch op
+ * sequence of the cited reference lines; the Python classes in perceptor_amd/
+ * (same names and signatures as the reference's) bind them through ctypes with
+ * tensor.data_ptr() and the current HIP stream.
+ *
+ * Conventions: plain pointers + sizes, caller owns every buffer (including
+ * workspaces), no global state, no C++ exceptions; return 0 on success,
+ * negative on error (PMI_ERR_ARG = -1 bad argument, PMI_ERR_LAUNCH = -2).
+ * All launches are asynchronous on `stream`.  Activations are NHWC
+ * ("pixel-major": [N][H*W][C]) 16-bit (dtype 0 = f16, 1 = bf16) unless noted;
+ * matrices are row-major with the contraction index contiguous.
+ */
+#ifndef PERCEPTOR_HIP_H
+#define PERCEPTOR_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pmi_stream_t; /* hipStream_t */
+
+int pmi_abi_version(void);
+
+/* ---- implicit-GEMM convolution / GEMM on MFMA ----------------------------------
+ * D[m][n] = act(alpha * sum_k A(m,k) * B[n][k] + bias[n] + nbias[m / hw][n]) + R[m][n]
+ * conv mode (taps == 9, stride 2, or up): m = (img, y, x) over the OUTPUT grid H x W,
+ * k = tap * Cin + c; A(m,k) gathers pixel (y*stride + dy, x*stride + dx) of the
+ * (optionally nearest-2x upsampled) input with zero padding.  Channels [0,C0) come
+ * from A0, [C0,C0+C1) from A1 (skip-concat without materialising torch.cat).
+ * Replaces: nn.Conv2d 3x3 / 1x1 / Conv1d k=1 / nn.Linear / einsum-bmm in
+ *   guided_diffusion/unet.py:232-252 (ResBlock), :294-300 (AttentionBlock qkv/proj),
+ *   :81-138 (Upsample/Downsample), :462-467 (time_embed), :650-652 (th.cat + conv),
+ *   velocity_diffusion/yfcc_2.py:17-28,52-70, cc12m_1.py:19-61, and the CLIP ViT
+ *   linears (ruclip/model.py:27-58,72-131) incl. their input-gradient GEMMs.        */
+typedef struct {
+  const void* A0; const void* A1; const void* B;
+  const float* bias;   /* [N] or NULL */
+  const float* nbias;  /* [M/hw][N] per-sample bias or NULL */
+  const void* R;       /* residual or NULL */
+  void* D;
+  int32_t M, N, K;     /* K % 8 == 0; N % 4 == 0 unless bias/nbias/R are NULL and ldd >= roundup(N,4) */
+  int32_t C0, C1;      /* channel split of the K index (C0 + C1 = Cin) */
+  int32_t lda0, lda1;  /* elements between consecutive pixels/rows of A0 / A1 */
+  int32_t ldb, ldd, ldr;
+  int32_t H, W, Hin, Win; /* conv mode only */
+  int32_t taps;        /* 1 or 9 */
+  int32_t stride;      /* 1 or 2 */
+  int32_t up;          /* nearest x2 upsample of the input (Hin = H/2) */
+  int32_t res_up;      /* residual is an [H/2 x W/2] grid read at (y>>1, x>>1): nearest x2 upsample of the skip path */
+  int32_t act;         /* PMI_ACT_* */
+  int32_t out_f32, res_f32;
+  int32_t hw;          /* pixels per sample for nbias (0 if unused) */
+  float alpha;
+  int32_t batch, batch_inner; /* grid.z batches: z -> (z / batch_inner, z % batch_inner) */
+  int64_t sA_o, sA_i, sB_o, sB_i, sD_o, sD_i, sR_o, sR_i; /* element strides */
+  int32_t dtype;       /* 0 f16, 1 bf16 */
+  int32_t ldnb;        /* row pitch of nbias (0 = N) */
+} pmi_igemm_args;
+int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream);
+
+/* ---- GroupNorm (+FiLM, +activation, +2x2 average pool) ---------------------------
+ * unet.py:232-252 / nn.py:17-19 (GroupNorm32 -> SiLU, FiLM h*(1+scale)+shift),
+ * yfcc_2.py:56 (GroupNorm(1,C)), cc12m_1.py:33-61 (GroupNorm(1,C,affine=False) + Modulation2d + ReLU).
+ * stats: partial sums per (sample, pixel-chunk, group) -> ws[N][nchunk][G][2] (fp32)
+ * finalize: coefficients a[n][c], b[n][c] so that y = act(x * a + b)
+ * apply: y (optionally 2x2 average-pooled after the activation)                      */
+/* x1/C0: optional second source: channels [0,C0) from x, [C0,C) from x1 (normalising a skip-concat, unet.py:650-652,
+ * without materialising it); pass x1 = NULL, C0 = C otherwise. */
+int pmi_gn_stats(const void* x, const void* x1, int C0, float* ws, int N, int HW, int C, int G, int nchunk, int dtype, pmi_stream_t s);
+int pmi_gn_finalize(const float* ws, const float* gamma, const float* beta, const float* film, int film_ld,
+                    float* coef_a, float* coef_b, int N, int HW, int C, int G, int nchunk, float eps, pmi_stream_t s);
+int pmi_gn_apply(const void* x, const void* x1, int C0, const float* coef_a, const float* coef_b, void* y, int N, int H, int W, int C,
+                 int act, int pool, int dtype, pmi_stream_t s);
+
+/* ---- attention, head dim 64 (flash-style, MFMA) -----------------------------------
+ * unet.py:332-348 (QKVAttentionLegacy), :364-382 (QKVAttention), yfcc_2.py:62-70.
+ * qkv_split re-tiles the qkv 1x1-conv output [N][T][3C] into Q,K [N*heads][Tp][64]
+ * and V^T [N*heads][64][Tp] (Tp = T rounded up to 32, zero filled).
+ * order: 0 = heads then q,k,v (legacy), 1 = q,k,v then heads (new order and v-diffusion). */
+int pmi_qkv_split(const void* qkv, void* q, void* k, void* vt, int N, int T, int heads, int order, int dtype, pmi_stream_t s);
+int pmi_attn_d64(const void* q, const void* k, const void* vt, void* out, int N, int T, int heads, float scale,
+                 int dtype, pmi_stream_t s);
+
+/* ---- layout / elementwise on the UNet path -----------------------------------------
+ * prep: images NCHW fp32 in [0,1] -> x = 2*img-1 (diffusion_space.py:1-2) as NHWC 16-bit with
+ *       Cpad channels; channels [3, 3+nplanes) are per-sample constants planes[n][j]
+ *       (yfcc_2.py:73-74,247-249 expand_to_planes of the Fourier timestep features).
+ * finish: NHWC (fp32, ld channels) -> NCHW fp32 first `cout` channels (guided_diffusion.py:125-133 [:, :3].float()) */
+int pmi_prep_input(const float* img, const float* planes, int nplanes, void* x, int N, int H, int W, int Cpad, int dtype, pmi_stream_t s);
+int pmi_finish_output(const float* y, int ld, float* out, int N, int H, int W, int cout, pmi_stream_t s);
+int pmi_avgpool2(const void* x, void* y, int N, int H, int W, int C, int dtype, pmi_stream_t s);            /* nn.AvgPool2d(2) */
+int pmi_upsample_bilinear2(const void* x, void* y, int N, int H, int W, int C, int dtype, pmi_stream_t s);  /* align_corners=False */
+/* nn.py:101-118 sinusoidal embedding [cos|sin] -> 16-bit [N][dim] */
+int pmi_timestep_embedding(const float* t, void* out, int N, int dim, float max_period, int dtype, pmi_stream_t s);
+/* yfcc_2.py:41-49 Fourier features: out[n] = [cos(2 pi t w_j) | sin(2 pi t w_j)] fp32 */
+int pmi_fourier_features(const float* t, const float* w, float* out, int N, int half, pmi_stream_t s);
+int pmi_cast_f32_to_16(const float* in, void* out, int64_t n, int act, int dtype, pmi_stream_t s);
+
+/* ---- sampler updates (fp32, NCHW, per-sample scalars) -------------------------------
+ * guided_diffusion/predictions.py:51-59,61-98 ; velocity_diffusion/predictions.py:50-62,68-105 ;
+ * guided: predictions.py:147-154 (both forms): p += scale * sigma_from * clamp(g,+-c)/c          */
+int pmi_ddim_eps_step(const float* img, const float* eps, const float* a_from, const float* s_from,
+                      const float* a_to, const float* s_to, float* next_img, float* denoised_img,
+                      int N, int64_t chw, pmi_stream_t s);
+int pmi_ddim_v_step(const float* img, const float* v, const float* a_from, const float* s_from,
+                    const float* a_to, const float* s_to, float* next_img, float* denoised_img,
+                    int N, int64_t chw, pmi_stream_t s);
+int pmi_guided_update(const float* pred, const float* grad, const float* s_from, float scale, float clamp_value,
+                      float* out, int N, int64_t chw, pmi_stream_t s);
+
+/* ---- CLIP guidance path (forward + input-gradient) ---------------------------------------
+ * ViT arithmetic: open-clip-torch 2.0.2 visual tower == OpenAI-CLIP VisionTransformer, in-tree copy
+ * ruclip/model.py:11-131; wrapper models/open_clip.py:109-123; loss losses/clip/clip.py:89-99.
+ * The linear layers (and their dX = dY * W input gradients) run on pmi_igemm; these are the
+ * memory-bound pieces between them.                                                           */
+/* LayerNorm (ruclip/model.py:11-17): fp32 rows -> 16-bit and/or fp32; mean_rstd = [mean[M] | rstd[M]] saved for bwd */
+int pmi_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y16, float* y32, float* mean_rstd,
+                      int M, int D, float eps, int dtype, pmi_stream_t s);
+/* input gradient; dy row r (stride dy_ld) belongs to row r*row_stride of x/gres/outputs; out = dx + gres */
+int pmi_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean_rstd, const float* gres,
+                      float* g32, void* g16, int M, int D, int dy_ld, int row_stride, int dtype, pmi_stream_t s);
+/* softmax over the first T columns of fp32 scores * scale -> 16-bit probabilities (zero padded to ld_out) */
+int pmi_softmax_fwd(const float* S, void* P, int rows, int T, int ld_in, int ld_out, float scale, int dtype, pmi_stream_t s);
+int pmi_softmax_bwd(const float* dP, const void* P, void* dS, int rows, int T, int ld_dp, int ld_p, float scale, int dtype, pmi_stream_t s);
+/* in[b][R][Cc] (row stride ld_in, batch offset (b/batch_inner)*sI_o + (b%batch_inner)*sI_i) -> out[b][Cc][Rp], Rp = R rounded up to 8 */
+int pmi_transpose_16(const void* in, void* out, int R, int Cc, int ld_in, int64_t sI_o, int64_t sI_i, int batch_inner, int batch, pmi_stream_t s);
+int pmi_act_bwd(const void* dh, const void* hpre, void* out, int64_t n, int act, int dtype, pmi_stream_t s); /* out = dh * act'(hpre) */
+/* transforms/resize/resize_right.py:34-189 as a banded operator along the middle axis of [outer][in_sz][inner]:
+ * out[o][j][i] = sum_t w[j][t] * in[o][idx[j][t]][i] (idx < 0 skipped).  The adjoint (image gradient) is the same call
+ * with the transposed band.  r0/r1 reserved (0). */
+int pmi_resize_apply(const float* in, float* out, const int* idx, const float* w, int outer, int in_sz, int inner, int out_sz,
+                     int taps, int r0, int r1, pmi_stream_t s);
+/* Normalize (models/open_clip.py:78-81) + patch conv as im2col (ruclip/model.py:84-90,105): col[N*g*g][Kp] 16-bit */
+int pmi_patchify(const float* img, const float* mean, const float* stdv, void* col, int N, int R, int P, int Kp, int r0, int dtype, pmi_stream_t s);
+int pmi_unpatchify(const float* dcol, const float* stdv, float* dimg, int N, int R, int P, int Kp, int r0, int r1, pmi_stream_t s);
+int pmi_vit_assemble(const float* emb, const float* cls, const float* pos, float* x, int N, int T, int D, int r0, pmi_stream_t s);
+/* losses/clip/clip.py:89-99 (+ F.normalize of models/open_clip.py:120-121): loss = mult * sum_{n,k} w_k 2 asin(|e_n-t_k|/2)^2 / (n_total*K);
+ * demb = gscale * dloss/demb (emb un-normalised).  n_total = global batch (>= N) so a sharded batch keeps the global mean. */
+int pmi_spherical_loss(const float* emb, const float* tgt, const float* wts, float* loss, float* demb, int N, int K, int D,
+                       int n_total, float mult, float gscale, pmi_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,49 @@
+"""Build libperceptor_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libperceptor_hip.so")
+SOURCES = ["igemm.hip", "norm.hip", "attn.hip", "elementwise.hip", "clip.hip"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
+
+
+def _stale(out: str, deps) -> bool:
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "..", "..", "include", "perceptor_hip.h")]
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+    objs = []
+
+    def compile_one(src):
+        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        os.makedirs(os.path.dirname(obj), exist_ok=True)
+        if force or _stale(obj, [os.path.join(HERE, src)] + hdrs):
+            cmd = [hipcc, *FLAGS, "-c", os.path.join(HERE, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,345 @@
+// CLIP-guidance path kernels around the MFMA GEMMs: LayerNorm fwd / input-grad, row softmax
+// fwd / bwd, 16-bit batched transpose, activation backward, separable resize (banded operator,
+// forward and adjoint share one kernel), patchify / unpatchify (Normalize fused), token assembly
+// and the spherical-distance loss with its gradient through F.normalize.
+#include "common.h"
+#include "../../include/perceptor_hip.h"
+
+namespace {
+
+inline int grid_for(int64_t work) {
+  int64_t b = (work + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+// ---- LayerNorm forward: one wave per row, fp32 in, 16-bit and/or fp32 out -------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, u16* __restrict__ y16,
+                                                            float* __restrict__ y32, float* __restrict__ mean_o,
+                                                            float* __restrict__ rstd_o, int M, int D, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (int64_t)row * D;
+  float s = 0.f;
+  for (int c = lane * 4; c < D; c += 256) { const float4 v = *(const float4*)(xr + c); s += v.x + v.y + v.z + v.w; }
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const float4 v = *(const float4*)(xr + c);
+    const float a = v.x - mean, b = v.y - mean, cc = v.z - mean, d = v.w - mean;
+    q += a * a + b * b + cc * cc + d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / D + eps);
+  if (lane == 0 && mean_o) { mean_o[row] = mean; rstd_o[row] = rstd; }
+  for (int c = lane * 4; c < D; c += 256) {
+    const float4 v = *(const float4*)(xr + c), g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+    const float o0 = (v.x - mean) * rstd * g.x + b.x, o1 = (v.y - mean) * rstd * g.y + b.y;
+    const float o2 = (v.z - mean) * rstd * g.z + b.z, o3 = (v.w - mean) * rstd * g.w + b.w;
+    if (y16) *(uint2*)(y16 + (int64_t)row * D + c) = pack4<T>(o0, o1, o2, o3);
+    if (y32) *(float4*)(y32 + (int64_t)row * D + c) = make_float4(o0, o1, o2, o3);
+  }
+}
+
+// dx = rstd * (gy - mean(gy) - xhat * mean(gy*xhat)), gy = dy*gamma ; out = dx + gres (fp32) and 16-bit copy
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean_i,
+                                                            const float* __restrict__ rstd_i, const float* __restrict__ gres,
+                                                            float* __restrict__ g32, u16* __restrict__ g16, int M, int D,
+                                                            int dy_ld, int row_stride) {
+  // row r of dy (stride dy_ld) corresponds to row r*row_stride of x / gres / outputs
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= M) return;
+  const int64_t row = (int64_t)r * row_stride;
+  const float* dyr = dy + (int64_t)r * dy_ld;
+  const float* xr = x + row * D;
+  const float mean = mean_i[r], rstd = rstd_i[r];
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    const float gy = dyr[c] * gamma[c], xh = (xr[c] - mean) * rstd;
+    s1 += gy; s2 += gy * xh;
+  }
+  s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+  for (int c = lane; c < D; c += 64) {
+    const float gy = dyr[c] * gamma[c], xh = (xr[c] - mean) * rstd;
+    float v = rstd * (gy - s1 - xh * s2);
+    if (gres) v += gres[row * D + c];
+    if (g32) g32[row * D + c] = v;
+    if (g16) g16[row * D + c] = T::from_f(v);
+  }
+}
+
+// ---- row softmax over the first T columns of fp32 scores; 16-bit probabilities, zero padding -----
+template <typename TT>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, u16* __restrict__ P, int rows, int T,
+                                                          int ld_in, int ld_out, float scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* sr = S + (int64_t)row * ld_in;
+  float mx = -1e30f;
+  for (int c = lane; c < T; c += 64) mx = fmaxf(mx, sr[c] * scale);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int c = lane; c < T; c += 64) sum += __expf(sr[c] * scale - mx);
+  const float inv = 1.f / wave_sum(sum);
+  for (int c = lane; c < ld_out; c += 64)
+    P[(int64_t)row * ld_out + c] = c < T ? TT::from_f(__expf(sr[c] * scale - mx) * inv) : (u16)0;
+}
+
+// dS = scale * P * (dP - sum_s dP*P)
+template <typename TT>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ dP, const u16* __restrict__ P,
+                                                          u16* __restrict__ dS, int rows, int T, int ld_dp, int ld_p, float scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* dr = dP + (int64_t)row * ld_dp;
+  const u16* pr = P + (int64_t)row * ld_p;
+  float dot = 0.f;
+  for (int c = lane; c < T; c += 64) dot += dr[c] * TT::to_f(pr[c]);
+  dot = wave_sum(dot);
+  for (int c = lane; c < ld_p; c += 64)
+    dS[(int64_t)row * ld_p + c] = c < T ? TT::from_f(scale * TT::to_f(pr[c]) * (dr[c] - dot)) : (u16)0;
+}
+
+// ---- batched transpose of 16-bit matrices: in[b][R][Cc] (strided) -> out[b][Cc][Rp], zero padded ----
+__global__ __launch_bounds__(256) void transpose16_kernel(const u16* __restrict__ in, u16* __restrict__ out, int R, int Cc,
+                                                          int ld_in, int64_t sI_o, int64_t sI_i, int batch_inner, int Rp) {
+  __shared__ u16 tile[32][34];
+  const int b = blockIdx.z, zo = b / batch_inner, zi = b - zo * batch_inner;
+  const u16* src = in + zo * sI_o + zi * sI_i;
+  u16* dst = out + (int64_t)b * Cc * Rp;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < Cc) ? src[(int64_t)r * ld_in + c] : (u16)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < Cc && r < Rp) dst[(int64_t)c * Rp + r] = tile[tx][i];
+  }
+}
+
+__device__ __forceinline__ float act_grad(float x, int act) {
+  switch (act) {
+    case PMI_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case PMI_ACT_SILU: { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
+    case PMI_ACT_GELU: return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    case PMI_ACT_QUICKGELU: { const float s = 1.f / (1.f + __expf(-1.702f * x)); return s * (1.f + 1.702f * x * (1.f - s)); }
+    default: return 1.f;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const u16* __restrict__ dh, const u16* __restrict__ hpre,
+                                                      u16* __restrict__ out, int64_t n8, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    float a[8], b[8];
+    unpack8<T>(*(const uint4*)(dh + i * 8), a);
+    unpack8<T>(*(const uint4*)(hpre + i * 8), b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] *= act_grad(b[e], act);
+    *(uint4*)(out + i * 8) = pack8<T>(a);
+  }
+}
+
+// ---- banded 1-D linear operator along the middle axis of [outer][in_sz][inner] ------------------
+__global__ __launch_bounds__(256) void resize_apply_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           const int* __restrict__ idx, const float* __restrict__ w,
+                                                           int outer, int in_sz, int inner, int out_sz, int taps) {
+  const int64_t total = (int64_t)outer * out_sz * inner;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ii = (int)(i % inner);
+    const int64_t t = i / inner;
+    const int j = (int)(t % out_sz);
+    const int64_t o = t / out_sz;
+    const float* base = in + o * in_sz * inner + ii;
+    float acc = 0.f;
+    for (int k = 0; k < taps; ++k) {
+      const int r = idx[j * taps + k];
+      if (r >= 0) acc += w[j * taps + k] * base[(int64_t)r * inner];
+    }
+    out[i] = acc;
+  }
+}
+
+// resized fp32 NCHW [N][3][R][R] -> im2col [N*g*g][Kp] 16-bit, k = c*P*P + py*P + px, (x-mean)/std fused
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, const float* __restrict__ mean,
+                                                       const float* __restrict__ stdv, u16* __restrict__ col, int N, int R,
+                                                       int P, int Kp) {
+  const int g = R / P, K = 3 * P * P;
+  const int64_t total = (int64_t)N * g * g * Kp;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i % Kp);
+    const int64_t m = i / Kp;
+    float v = 0.f;
+    if (k < K) {
+      const int c = k / (P * P), rem = k - c * P * P, py = rem / P, px = rem - py * P;
+      const int n = (int)(m / (g * g)), pp = (int)(m - (int64_t)n * g * g), gy = pp / g, gx = pp - gy * g;
+      v = (img[(((int64_t)n * 3 + c) * R + gy * P + py) * R + gx * P + px] - mean[c]) / stdv[c];
+    }
+    col[i] = T::from_f(v);
+  }
+}
+__global__ __launch_bounds__(256) void unpatchify_kernel(const float* __restrict__ dcol, const float* __restrict__ stdv,
+                                                         float* __restrict__ dimg, int N, int R, int P, int Kp, float mul) {
+  const int g = R / P;
+  const int64_t total = (int64_t)N * 3 * R * R;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int x = (int)(i % R), y = (int)((i / R) % R), c = (int)((i / ((int64_t)R * R)) % 3), n = (int)(i / ((int64_t)3 * R * R));
+    const int gy = y / P, py = y - gy * P, gx = x / P, px = x - gx * P;
+    const int64_t m = (int64_t)n * g * g + gy * g + gx;
+    dimg[i] = dcol[m * Kp + c * P * P + py * P + px] / stdv[c] * mul;
+  }
+}
+
+// x[n][0] = cls + pos[0]; x[n][1+p] = emb[n][p] + pos[1+p]  (fp32)
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ emb, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, float* __restrict__ x, int N, int T, int D) {
+  const int64_t total = (int64_t)N * T * D;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int d = (int)(i % D), t = (int)((i / D) % T), n = (int)(i / ((int64_t)T * D));
+    x[i] = (t == 0 ? cls[d] : emb[((int64_t)n * (T - 1) + t - 1) * D + d]) + pos[(int64_t)t * D + d];
+  }
+}
+
+// loss = mult * mean_{n,k} w_k * 2 asin(|e_n - t_k| / 2)^2, e = emb/|emb| ; demb = gradient wrt emb (x gscale)
+__global__ __launch_bounds__(256) void spherical_loss_kernel(const float* __restrict__ emb, const float* __restrict__ tgt,
+                                                             const float* __restrict__ wts, float* __restrict__ loss,
+                                                             float* __restrict__ demb, int N, int K, int D, float mult,
+                                                             float gscale, float inv_count) {
+  __shared__ float red[4];
+  __shared__ float e_s[2048], g_s[2048];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+  };
+  float s = 0.f;
+  for (int d = tid; d < D; d += 256) { const float v = emb[(int64_t)n * D + d]; s += v * v; }
+  const float nrm = fmaxf(sqrtf(block_sum(s)), 1e-12f);
+  for (int d = tid; d < D; d += 256) { e_s[d] = emb[(int64_t)n * D + d] / nrm; g_s[d] = 0.f; }
+  __syncthreads();
+  float lsum = 0.f;
+  for (int k = 0; k < K; ++k) {
+    float q = 0.f;
+    for (int d = tid; d < D; d += 256) { const float df = e_s[d] - tgt[(int64_t)k * D + d]; q += df * df; }
+    const float u = sqrtf(block_sum(q));
+    const float hs = fminf(u * 0.5f, 1.f);
+    const float as = asinf(hs);
+    lsum += wts[k] * 2.f * as * as;
+    // d/du [2 asin(u/2)^2] = 2 asin(u/2) / sqrt(1 - u^2/4); times (e - t)/u
+    const float coef = u > 1e-12f ? wts[k] * 2.f * as / (sqrtf(fmaxf(1.f - hs * hs, 1e-12f)) * u) : 0.f;
+    for (int d = tid; d < D; d += 256) g_s[d] += coef * (e_s[d] - tgt[(int64_t)k * D + d]);
+    __syncthreads();
+  }
+  float dot = 0.f;
+  for (int d = tid; d < D; d += 256) dot += e_s[d] * g_s[d];
+  dot = block_sum(dot);
+  const float c = mult * inv_count * gscale / nrm;
+  for (int d = tid; d < D; d += 256) demb[(int64_t)n * D + d] = c * (g_s[d] - e_s[d] * dot);
+  if (tid == 0) atomicAdd(loss, lsum * mult * inv_count);
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)s)
+#define BY_DTYPE(KERN, ...)                                                                    \
+  do {                                                                                         \
+    if (dtype == PMI_DT_BF16) hipLaunchKernelGGL(KERN<BF16>, grid, block, 0, ST, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERN<F16>, grid, block, 0, ST, __VA_ARGS__);                       \
+  } while (0)
+
+extern "C" int pmi_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y16, float* y32, float* mean_rstd,
+                                 int M, int D, float eps, int dtype, pmi_stream_t s) {
+  if (!x || !gamma || !beta || (!y16 && !y32) || M <= 0 || D <= 0 || (D & 3)) return PMI_ERR_ARG;
+  dim3 grid((M + 3) / 4), block(256);
+  float* mo = mean_rstd; float* ro = mean_rstd ? mean_rstd + M : nullptr;
+  BY_DTYPE(layernorm_fwd_kernel, x, gamma, beta, (u16*)y16, y32, mo, ro, M, D, eps);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean_rstd, const float* gres,
+                                 float* g32, void* g16, int M, int D, int dy_ld, int row_stride, int dtype, pmi_stream_t s) {
+  if (!dy || !x || !gamma || !mean_rstd || (!g32 && !g16) || M <= 0 || D <= 0) return PMI_ERR_ARG;
+  dim3 grid((M + 3) / 4), block(256);
+  BY_DTYPE(layernorm_bwd_kernel, dy, x, gamma, mean_rstd, mean_rstd + M, gres, g32, (u16*)g16, M, D, dy_ld, row_stride);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_softmax_fwd(const float* S, void* P, int rows, int T, int ld_in, int ld_out, float scale, int dtype, pmi_stream_t s) {
+  if (!S || !P || rows <= 0 || T <= 0 || ld_in < T || ld_out < T) return PMI_ERR_ARG;
+  dim3 grid((rows + 3) / 4), block(256);
+  BY_DTYPE(softmax_fwd_kernel, S, (u16*)P, rows, T, ld_in, ld_out, scale);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_softmax_bwd(const float* dP, const void* P, void* dS, int rows, int T, int ld_dp, int ld_p, float scale, int dtype, pmi_stream_t s) {
+  if (!dP || !P || !dS || rows <= 0 || T <= 0 || ld_dp < T || ld_p < T) return PMI_ERR_ARG;
+  dim3 grid((rows + 3) / 4), block(256);
+  BY_DTYPE(softmax_bwd_kernel, dP, (const u16*)P, (u16*)dS, rows, T, ld_dp, ld_p, scale);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_transpose_16(const void* in, void* out, int R, int Cc, int ld_in, int64_t sI_o, int64_t sI_i, int batch_inner,
+                                int batch, pmi_stream_t s) {
+  if (!in || !out || R <= 0 || Cc <= 0 || batch <= 0 || batch_inner <= 0) return PMI_ERR_ARG;
+  const int Rp = (R + 7) / 8 * 8;
+  dim3 grid((Cc + 31) / 32, (Rp + 31) / 32, batch), block(256);
+  hipLaunchKernelGGL(transpose16_kernel, grid, block, 0, ST, (const u16*)in, (u16*)out, R, Cc, ld_in, sI_o, sI_i, batch_inner, Rp);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_act_bwd(const void* dh, const void* hpre, void* out, int64_t n, int act, int dtype, pmi_stream_t s) {
+  if (!dh || !hpre || !out || n <= 0 || (n & 7)) return PMI_ERR_ARG;
+  dim3 grid(grid_for(n / 8)), block(256);
+  BY_DTYPE(act_bwd_kernel, (const u16*)dh, (const u16*)hpre, (u16*)out, n / 8, act);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_resize_apply(const float* in, float* out, const int* idx, const float* w, int outer, int in_sz, int inner,
+                                int out_sz, int taps, int r0, int r1, pmi_stream_t s) {
+  (void)r0; (void)r1;
+  if (!in || !out || !idx || !w || outer <= 0 || in_sz <= 0 || inner <= 0 || out_sz <= 0 || taps <= 0) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(resize_apply_kernel, dim3(grid_for((int64_t)outer * out_sz * inner)), dim3(256), 0, ST, in, out, idx, w,
+                     outer, in_sz, inner, out_sz, taps);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_patchify(const float* img, const float* mean, const float* stdv, void* col, int N, int R, int P, int Kp,
+                            int r0, int dtype, pmi_stream_t s) {
+  (void)r0;
+  if (!img || !mean || !stdv || !col || N <= 0 || R <= 0 || P <= 0 || R % P || Kp < 3 * P * P || (Kp & 7)) return PMI_ERR_ARG;
+  dim3 grid(grid_for((int64_t)N * (R / P) * (R / P) * Kp)), block(256);
+  BY_DTYPE(patchify_kernel, img, mean, stdv, (u16*)col, N, R, P, Kp);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_unpatchify(const float* dcol, const float* stdv, float* dimg, int N, int R, int P, int Kp, int r0, int r1, pmi_stream_t s) {
+  (void)r0; (void)r1;
+  if (!dcol || !stdv || !dimg || N <= 0 || R % P) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(unpatchify_kernel, dim3(grid_for((int64_t)N * 3 * R * R)), dim3(256), 0, ST, dcol, stdv, dimg, N, R, P, Kp, 1.0f);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_vit_assemble(const float* emb, const float* cls, const float* pos, float* x, int N, int T, int D, int r0, pmi_stream_t s) {
+  (void)r0;
+  if (!emb || !cls || !pos || !x || N <= 0 || T <= 1 || D <= 0) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(vit_assemble_kernel, dim3(grid_for((int64_t)N * T * D)), dim3(256), 0, ST, emb, cls, pos, x, N, T, D);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_spherical_loss(const float* emb, const float* tgt, const float* wts, float* loss, float* demb, int N, int K,
+                                  int D, int n_total, float mult, float gscale, pmi_stream_t s) {
+  if (!emb || !tgt || !wts || !loss || !demb || N <= 0 || K <= 0 || D <= 0 || D > 2048 || n_total < N) return PMI_ERR_ARG;
+  if (hipMemsetAsync(loss, 0, sizeof(float), ST) != hipSuccess) return PMI_ERR_LAUNCH;
+  hipLaunchKernelGGL(spherical_loss_kernel, dim3(N), dim3(256), 0, ST, emb, tgt, wts, loss, demb, N, K, D, mult, gscale,
+                     1.0f / ((float)n_total * (float)K));
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}

@@ -1,0 +1,99 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels.  wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PMI_OK 0
+#define PMI_ERR_ARG (-1)
+#define PMI_ERR_LAUNCH (-2)
+
+#define PMI_DT_F16 0
+#define PMI_DT_BF16 1
+
+#define PMI_ACT_NONE 0
+#define PMI_ACT_RELU 1
+#define PMI_ACT_SILU 2
+#define PMI_ACT_GELU 3
+#define PMI_ACT_QUICKGELU 4
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+struct F16 {
+  using elem = _Float16;
+  using vec8 = f16x8;
+  static __device__ __forceinline__ float to_f(u16 v) { return (float)__builtin_bit_cast(_Float16, v); }
+  static __device__ __forceinline__ u16 from_f(float f) { return __builtin_bit_cast(u16, (_Float16)f); }
+  static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+struct BF16 {
+  using elem = __bf16;
+  using vec8 = bf16x8;
+  static __device__ __forceinline__ float to_f(u16 v) { return __builtin_bit_cast(float, ((uint32_t)v) << 16); }
+  static __device__ __forceinline__ u16 from_f(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
+  static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ void unpack8(uint4 v, float* f) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = T::to_f((u16)(w[i] & 0xffff));
+    f[2 * i + 1] = T::to_f((u16)(w[i] >> 16));
+  }
+}
+template <typename T>
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)T::from_f(f[2 * i]) | ((uint32_t)T::from_f(f[2 * i + 1]) << 16);
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+template <typename T>
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+  return make_uint2((uint32_t)T::from_f(a) | ((uint32_t)T::from_f(b) << 16),
+                    (uint32_t)T::from_f(c) | ((uint32_t)T::from_f(d) << 16));
+}
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+  switch (act) {
+    case PMI_ACT_RELU: return x > 0.f ? x : 0.f;
+    case PMI_ACT_SILU: return x / (1.f + __expf(-x));
+    case PMI_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+    case PMI_ACT_QUICKGELU: return x / (1.f + __expf(-1.702f * x));
+    default: return x;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// Bijective XCD-aware remap of a linear workgroup id: workgroups that share an
+// XCD (same id % 8 under round-robin dispatch) get a contiguous range of tiles.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+#define PMI_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) return PMI_ERR_LAUNCH;            \
+  } while (0)

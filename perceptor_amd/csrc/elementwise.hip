@@ -1,0 +1,237 @@
+// Layout conversion, pooling / upsampling, timestep features and the fused sampler updates.
+// All HBM-bound streaming kernels: grid-stride, 16-byte accesses where the layout allows.
+#include "common.h"
+#include "../../include/perceptor_hip.h"
+
+namespace {
+
+inline int grid_for(int64_t work) {
+  int64_t b = (work + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+// NCHW fp32 image in [0,1] -> NHWC 16-bit x = 2*img-1, channels [3,3+nplanes) constant planes, rest zero.
+template <typename T>
+__global__ __launch_bounds__(256) void prep_input_kernel(const float* __restrict__ img, const float* __restrict__ planes,
+                                                         int nplanes, u16* __restrict__ x, int N, int HW, int Cpad) {
+  const int C8 = Cpad >> 3;
+  const int64_t total = (int64_t)N * HW * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int n = (int)(pix / HW);
+    const int64_t p = pix - (int64_t)n * HW;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c8 * 8 + e;
+      float v = 0.f;
+      if (c < 3) v = img[((int64_t)n * 3 + c) * HW + p] * 2.f - 1.f;
+      else if (c < 3 + nplanes) v = planes[(int64_t)n * nplanes + (c - 3)];
+      f[e] = v;
+    }
+    *(uint4*)(x + pix * Cpad + c8 * 8) = pack8<T>(f);
+  }
+}
+
+__global__ __launch_bounds__(256) void finish_output_kernel(const float* __restrict__ y, int ld, float* __restrict__ out,
+                                                            int N, int HW, int cout) {
+  const int64_t total = (int64_t)N * cout * HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i % HW;
+    const int64_t nc = i / HW;
+    const int c = (int)(nc % cout), n = (int)(nc / cout);
+    out[i] = y[((int64_t)n * HW + p) * ld + c];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool2_kernel(const u16* __restrict__ x, u16* __restrict__ y, int N, int H, int W, int C) {
+  const int C8 = C >> 3, Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)N * Ho * Wo * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int n = (int)(pix / ((int64_t)Ho * Wo));
+    const int rem = (int)(pix - (int64_t)n * Ho * Wo);
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    const u16* b = x + (((int64_t)n * H + 2 * oy) * W + 2 * ox) * C + c8 * 8;
+    float a0[8], a1[8], a2[8], a3[8], o[8];
+    unpack8<T>(*(const uint4*)b, a0); unpack8<T>(*(const uint4*)(b + C), a1);
+    unpack8<T>(*(const uint4*)(b + (int64_t)W * C), a2); unpack8<T>(*(const uint4*)(b + (int64_t)W * C + C), a3);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.25f * (a0[e] + a1[e] + a2[e] + a3[e]);
+    *(uint4*)(y + pix * C + c8 * 8) = pack8<T>(o);
+  }
+}
+
+// bilinear x2, align_corners=False: even o=2i -> .25 x[i-1] + .75 x[i]; odd o=2i+1 -> .75 x[i] + .25 x[i+1] (clamped)
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bilinear2_kernel(const u16* __restrict__ x, u16* __restrict__ y, int N, int H, int W, int C) {
+  const int C8 = C >> 3, Ho = H * 2, Wo = W * 2;
+  const int64_t total = (int64_t)N * Ho * Wo * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int n = (int)(pix / ((int64_t)Ho * Wo));
+    const int rem = (int)(pix - (int64_t)n * Ho * Wo);
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    const int iy = oy >> 1, ix = ox >> 1;
+    const int y1 = (oy & 1) ? min(iy + 1, H - 1) : max(iy - 1, 0);
+    const int x1 = (ox & 1) ? min(ix + 1, W - 1) : max(ix - 1, 0);
+    const u16* b = x + (int64_t)n * H * W * C + c8 * 8;
+    float a00[8], a01[8], a10[8], a11[8], o[8];
+    unpack8<T>(*(const uint4*)(b + ((int64_t)iy * W + ix) * C), a00);
+    unpack8<T>(*(const uint4*)(b + ((int64_t)iy * W + x1) * C), a01);
+    unpack8<T>(*(const uint4*)(b + ((int64_t)y1 * W + ix) * C), a10);
+    unpack8<T>(*(const uint4*)(b + ((int64_t)y1 * W + x1) * C), a11);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.75f * (0.75f * a00[e] + 0.25f * a01[e]) + 0.25f * (0.75f * a10[e] + 0.25f * a11[e]);
+    *(uint4*)(y + pix * C + c8 * 8) = pack8<T>(o);
+  }
+}
+
+template <typename T>
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, u16* __restrict__ out, int N, int dim, float max_period) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * half) return;
+  const int n = i / half, j = i - n * half;
+  const float freq = expf(-logf(max_period) * (float)j / (float)half);
+  const float arg = t[n] * freq;
+  out[(int64_t)n * dim + j] = T::from_f(cosf(arg));
+  out[(int64_t)n * dim + half + j] = T::from_f(sinf(arg));
+}
+
+__global__ void fourier_features_kernel(const float* __restrict__ t, const float* __restrict__ w, float* __restrict__ out, int N, int half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * half) return;
+  const int n = i / half, j = i - n * half;
+  const float f = 6.283185307179586f * t[n] * w[j];
+  out[(int64_t)n * 2 * half + j] = cosf(f);
+  out[(int64_t)n * 2 * half + half + j] = sinf(f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ in, u16* __restrict__ out, int64_t n, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = T::from_f(act_apply(in[i], act));
+}
+
+// x0 = (x - s_f*eps)/max(a_f,1e-7); x' = x0*a_t + eps*s_t ; images = (x+1)/2
+__global__ __launch_bounds__(256) void ddim_eps_kernel(const float* __restrict__ img, const float* __restrict__ eps,
+                                                       const float* af, const float* sf, const float* at, const float* st,
+                                                       float* __restrict__ next, float* __restrict__ den, int N, int64_t chw) {
+  const int64_t total = (int64_t)N * chw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int n = (int)(i / chw);
+    const float x = img[i] * 2.f - 1.f, e = eps[i];
+    const float x0 = (x - sf[n] * e) / fmaxf(af[n], 1e-7f);
+    if (next) next[i] = (x0 * at[n] + e * st[n] + 1.f) * 0.5f;
+    if (den) den[i] = (x0 + 1.f) * 0.5f;
+  }
+}
+
+// x0 = x*a_f - v*s_f ; eps = x*s_f + v*a_f ; x' = x0*a_t + eps*s_t
+__global__ __launch_bounds__(256) void ddim_v_kernel(const float* __restrict__ img, const float* __restrict__ v,
+                                                     const float* af, const float* sf, const float* at, const float* st,
+                                                     float* __restrict__ next, float* __restrict__ den, int N, int64_t chw) {
+  const int64_t total = (int64_t)N * chw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int n = (int)(i / chw);
+    const float x = img[i] * 2.f - 1.f, vv = v[i];
+    const float x0 = x * af[n] - vv * sf[n];
+    const float e = x * sf[n] + vv * af[n];
+    if (next) next[i] = (x0 * at[n] + e * st[n] + 1.f) * 0.5f;
+    if (den) den[i] = (x0 + 1.f) * 0.5f;
+  }
+}
+
+__global__ __launch_bounds__(256) void guided_kernel(const float* __restrict__ pred, const float* __restrict__ grad,
+                                                     const float* sf, float scale, float cv, float* __restrict__ out,
+                                                     int N, int64_t chw) {
+  const int64_t total = (int64_t)N * chw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int n = (int)(i / chw);
+    const float g = fminf(fmaxf(grad[i], -cv), cv);
+    out[i] = pred[i] + scale * sf[n] * g / cv;
+  }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)s)
+#define BY_DTYPE(KERN, ...)                                                              \
+  do {                                                                                   \
+    if (dtype == PMI_DT_BF16) hipLaunchKernelGGL(KERN<BF16>, grid, block, 0, ST, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERN<F16>, grid, block, 0, ST, __VA_ARGS__);                 \
+  } while (0)
+
+extern "C" int pmi_prep_input(const float* img, const float* planes, int nplanes, void* x, int N, int H, int W, int Cpad, int dtype, pmi_stream_t s) {
+  if (!img || !x || N <= 0 || H <= 0 || W <= 0 || (Cpad & 7) || Cpad < 3 + nplanes || (nplanes > 0 && !planes)) return PMI_ERR_ARG;
+  dim3 grid(grid_for((int64_t)N * H * W * (Cpad / 8))), block(256);
+  BY_DTYPE(prep_input_kernel, img, planes, nplanes, (u16*)x, N, H * W, Cpad);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_finish_output(const float* y, int ld, float* out, int N, int H, int W, int cout, pmi_stream_t s) {
+  if (!y || !out || N <= 0 || cout <= 0 || cout > ld) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(finish_output_kernel, dim3(grid_for((int64_t)N * cout * H * W)), dim3(256), 0, ST, y, ld, out, N, H * W, cout);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_avgpool2(const void* x, void* y, int N, int H, int W, int C, int dtype, pmi_stream_t s) {
+  if (!x || !y || N <= 0 || (H & 1) || (W & 1) || (C & 7)) return PMI_ERR_ARG;
+  dim3 grid(grid_for((int64_t)N * (H / 2) * (W / 2) * (C / 8))), block(256);
+  BY_DTYPE(avgpool2_kernel, (const u16*)x, (u16*)y, N, H, W, C);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_upsample_bilinear2(const void* x, void* y, int N, int H, int W, int C, int dtype, pmi_stream_t s) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || (C & 7)) return PMI_ERR_ARG;
+  dim3 grid(grid_for((int64_t)N * H * W * 4 * (C / 8))), block(256);
+  BY_DTYPE(upsample_bilinear2_kernel, (const u16*)x, (u16*)y, N, H, W, C);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_timestep_embedding(const float* t, void* out, int N, int dim, float max_period, int dtype, pmi_stream_t s) {
+  if (!t || !out || N <= 0 || dim <= 0 || (dim & 1)) return PMI_ERR_ARG;
+  dim3 grid((N * dim / 2 + 255) / 256), block(256);
+  BY_DTYPE(timestep_embedding_kernel, t, (u16*)out, N, dim, max_period);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_fourier_features(const float* t, const float* w, float* out, int N, int half, pmi_stream_t s) {
+  if (!t || !w || !out || N <= 0 || half <= 0) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(fourier_features_kernel, dim3((N * half + 255) / 256), dim3(256), 0, ST, t, w, out, N, half);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_cast_f32_to_16(const float* in, void* out, int64_t n, int act, int dtype, pmi_stream_t s) {
+  if (!in || !out || n <= 0) return PMI_ERR_ARG;
+  dim3 grid(grid_for(n)), block(256);
+  BY_DTYPE(cast_kernel, in, (u16*)out, n, act);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_ddim_eps_step(const float* img, const float* eps, const float* a_from, const float* s_from, const float* a_to,
+                                 const float* s_to, float* next_img, float* denoised_img, int N, int64_t chw, pmi_stream_t s) {
+  if (!img || !eps || !a_from || !s_from || N <= 0 || chw <= 0 || (next_img && (!a_to || !s_to))) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(ddim_eps_kernel, dim3(grid_for(N * chw)), dim3(256), 0, ST, img, eps, a_from, s_from, a_to, s_to, next_img, denoised_img, N, chw);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_ddim_v_step(const float* img, const float* v, const float* a_from, const float* s_from, const float* a_to,
+                               const float* s_to, float* next_img, float* denoised_img, int N, int64_t chw, pmi_stream_t s) {
+  if (!img || !v || !a_from || !s_from || N <= 0 || chw <= 0 || (next_img && (!a_to || !s_to))) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(ddim_v_kernel, dim3(grid_for(N * chw)), dim3(256), 0, ST, img, v, a_from, s_from, a_to, s_to, next_img, denoised_img, N, chw);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_guided_update(const float* pred, const float* grad, const float* s_from, float scale, float clamp_value,
+                                 float* out, int N, int64_t chw, pmi_stream_t s) {
+  if (!pred || !grad || !s_from || !out || N <= 0 || chw <= 0 || !(clamp_value > 0.f)) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(guided_kernel, dim3(grid_for(N * chw)), dim3(256), 0, ST, pred, grad, s_from, scale, clamp_value, out, N, chw);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}

@@ -1,0 +1,252 @@
+// Implicit-GEMM convolution / GEMM for gfx950 on v_mfma_f32_32x32x16_{f16,bf16}.
+//
+//   D[m][n] = act(alpha * sum_k A(m,k) * B[n][k] + bias[n] + nbias[m/hw][n]) + R[m][n]
+//
+// Tile 128 (pixels) x 128 (output channels) x 64 (k) per 256-thread workgroup, 4 waves as
+// 2 x 2, each wave a 64 x 64 sub-tile = 2 x 2 MFMA blocks of 32 x 32 (fp32 accumulate).
+// The product is computed "swapped" (MFMA A operand = weights, B operand = activations) so
+// an accumulator lane holds 4 consecutive output channels of one pixel: NHWC epilogue
+// stores are 8-byte (16-bit out) or 16-byte (fp32 out) vectors.
+// LDS: two stages x (16 KiB activations + 16 KiB weights) = 64 KiB -> 2 workgroups per CU.
+// Rows are 128 B (64 k-elements); the 16-byte chunk index is XOR-swizzled with (row>>1)&7
+// so both the ds_write_b128 staging and the ds_read_b128 fragment reads are conflict-free.
+// Global->LDS goes through registers (gathered addresses + zero fill for the conv halo);
+// the loads of k-tile t+1 are issued before the MFMAs of tile t and written after them.
+#include "common.h"
+#include "../../include/perceptor_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 128;        // one operand tile: 128 rows x 128 B
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;  // activations + weights
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T, bool CONV, bool KFAST>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
+  const int logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
+
+  const u16* A0 = (const u16*)a.A0;
+  const u16* A1 = (const u16*)a.A1;
+  const u16* Bw = (const u16*)a.B;
+  int64_t offD = 0, offR = 0;
+  if (a.batch > 1) {
+    const int zo = blockIdx.z / a.batch_inner, zi = blockIdx.z % a.batch_inner;
+    A0 += zo * a.sA_o + zi * a.sA_i;
+    Bw += zo * a.sB_o + zi * a.sB_i;
+    offD = zo * a.sD_o + zi * a.sD_i;
+    offR = zo * a.sR_o + zi * a.sR_i;
+  }
+
+  // ---- per-thread staging coordinates: 4 rows x one 16-byte chunk of each operand tile ----
+  const int srow = tid >> 3, sc = tid & 7;
+  const int Cin = a.C0 + a.C1;
+  const int Hv = a.up ? a.Hin * 2 : a.Hin, Wv = a.up ? a.Win * 2 : a.Win;
+  int ys[4], xs[4], nb[4];
+  int64_t arow[4];
+  int64_t brow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + srow + 32 * i;
+    if (CONV) {
+      if (m < a.M) {
+        const int hw = a.H * a.W;
+        const int img = m / hw, rem = m - img * hw;
+        const int y = rem / a.W, x = rem - y * a.W;
+        ys[i] = y * a.stride; xs[i] = x * a.stride; nb[i] = img * a.Hin;
+      } else {
+        ys[i] = -(1 << 20); xs[i] = 0; nb[i] = 0;
+      }
+    } else {
+      arow[i] = m < a.M ? (int64_t)m : -1;
+    }
+    const int n = n0 + srow + 32 * i;
+    brow[i] = n < a.N ? (int64_t)n * a.ldb : -1;
+  }
+
+  uint4 ra[4], rb[4];
+  int tap_u = 0, ci_u = 0;  // KFAST: uniform (tap, channel) of the next k-tile to load
+
+  auto load_tile = [&](int kt) {
+    const int k = kt * BK + sc * 8;
+    const bool kok = k < a.K;
+    int tap, ci;
+    if (KFAST) {
+      tap = tap_u; ci = ci_u + sc * 8;
+      ci_u += BK;
+      if (ci_u >= Cin) { ci_u -= Cin; ++tap_u; }
+    } else {
+      tap = k / Cin; ci = k - tap * Cin;
+    }
+    const bool second = ci >= a.C0;
+    const u16* base = second ? A1 : A0;
+    const int ld = second ? a.lda1 : a.lda0;
+    const int cc = second ? ci - a.C0 : ci;
+    int dy = 0, dx = 0;
+    if (CONV && a.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (CONV) {
+        int iy = ys[i] + dy, ix = xs[i] + dx;
+        if (kok && iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) {
+          if (a.up) { iy >>= 1; ix >>= 1; }
+          v = *(const uint4*)(base + ((int64_t)(nb[i] + iy) * a.Win + ix) * ld + cc);
+        }
+      } else {
+        if (kok && arow[i] >= 0) v = *(const uint4*)(base + arow[i] * ld + cc);
+      }
+      ra[i] = v;
+      uint4 w = make_uint4(0, 0, 0, 0);
+      if (kok && brow[i] >= 0) w = *(const uint4*)(Bw + brow[i] + k);
+      rb[i] = w;
+    }
+  };
+  auto store_tile = [&](int stage) {
+    char* sa = smem + stage * STAGE_BYTES;
+    char* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int off = lds_off(srow + 32 * i, sc);
+      *(uint4*)(sa + off) = ra[i];
+      *(uint4*)(sb + off) = rb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (a.K + BK - 1) / BK;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const char* sa = smem + (kt & 1) * STAGE_BYTES;
+    const char* sb = sa + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int ch = kk * 2 + lhi;
+      uint4 xf[2], wf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) xf[i] = *(const uint4*)(sa + lds_off(wr * 64 + i * 32 + l31, ch));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[j] = *(const uint4*)(sb + lds_off(wc * 64 + j * 32 + l31, ch));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma32(wf[j], xf[i], acc[i][j]);
+    }
+    if (kt + 1 < nk) store_tile((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane = pixel (col), registers = 4 consecutive output channels x 4 groups ----
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wr * 64 + i * 32 + l31;
+    if (m >= a.M) continue;
+    int64_t rrow = (int64_t)m * a.ldr;
+    if (a.R && a.res_up) {
+      const int hw = a.H * a.W;
+      const int img = m / hw, rem = m - img * hw;
+      const int y = rem / a.W, x = rem - y * a.W;
+      rrow = ((int64_t)(img * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.ldr;
+    }
+    const float* nbp = a.nbias ? a.nbias + (int64_t)(m / a.hw) * (a.ldnb ? a.ldnb : a.N) : nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wc * 64 + j * 32 + 4 * lhi + 8 * g;
+        if (n >= a.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * a.alpha;
+        if (a.bias) {
+          const float4 b = *(const float4*)(a.bias + n);
+          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (nbp) {
+          const float4 b = *(const float4*)(nbp + n);
+          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (a.act != PMI_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
+        }
+        if (a.R) {
+          if (a.res_f32) {
+            const float4 r = *(const float4*)((const float*)a.R + offR + rrow + n);
+            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+          } else {
+            const uint2 r = *(const uint2*)((const u16*)a.R + offR + rrow + n);
+            v[0] += T::to_f((u16)(r.x & 0xffff)); v[1] += T::to_f((u16)(r.x >> 16));
+            v[2] += T::to_f((u16)(r.y & 0xffff)); v[3] += T::to_f((u16)(r.y >> 16));
+          }
+        }
+        const int64_t o = offD + (int64_t)m * a.ldd + n;
+        if (a.out_f32) *(float4*)((float*)a.D + o) = make_float4(v[0], v[1], v[2], v[3]);
+        else *(uint2*)((u16*)a.D + o) = pack4<T>(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch(const pmi_igemm_args& a, hipStream_t s) {
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  const dim3 grid(tiles, 1, a.batch > 1 ? a.batch : 1), block(256);
+  const bool conv = a.taps == 9 || a.up || a.stride == 2;
+  const int Cin = a.C0 + a.C1;
+  const bool kfast = (Cin % BK == 0) && (a.C0 % BK == 0);
+  if (conv) {
+    if (kfast) hipLaunchKernelGGL((igemm_kernel<T, true, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((igemm_kernel<T, true, false>), grid, block, 0, s, a);
+  } else {
+    if (kfast) hipLaunchKernelGGL((igemm_kernel<T, false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((igemm_kernel<T, false, false>), grid, block, 0, s, a);
+  }
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+
+}  // namespace
+
+extern "C" int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream) {
+  if (!a || !a->A0 || !a->B || !a->D) return PMI_ERR_ARG;
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0) return PMI_ERR_ARG;
+  if ((a->K & 7) || (a->C0 & 7) || (a->C1 & 7)) return PMI_ERR_ARG;
+  // a ragged N (attention scores) is allowed when the 4-wide epilogue vectors stay inside the row pitch
+  if ((a->N & 3) && (a->bias || a->nbias || a->R || a->ldd < ((a->N + 3) & ~3))) return PMI_ERR_ARG;
+  if ((a->lda0 & 7) || (a->ldb & 7) || (a->ldd & 3)) return PMI_ERR_ARG;
+  if (a->C1 > 0 && (!a->A1 || (a->lda1 & 7))) return PMI_ERR_ARG;
+  if (a->taps != 1 && a->taps != 9) return PMI_ERR_ARG;
+  if (a->stride != 1 && a->stride != 2) return PMI_ERR_ARG;
+  if (a->K != a->taps * (a->C0 + a->C1)) return PMI_ERR_ARG;
+  if (a->R && (a->ldr & 3)) return PMI_ERR_ARG;
+  if (a->nbias && a->hw <= 0) return PMI_ERR_ARG;
+  const bool conv = a->taps == 9 || a->up || a->stride == 2;
+  if (a->res_up && ((a->H & 1) || (a->W & 1))) return PMI_ERR_ARG;
+  if ((conv || a->res_up) && (a->H <= 0 || a->W <= 0 || a->Hin <= 0 || a->Win <= 0 || a->M % (a->H * a->W))) return PMI_ERR_ARG;
+  if (a->up && (a->H != 2 * a->Hin || a->W != 2 * a->Win)) return PMI_ERR_ARG;
+  if (a->batch > 1 && a->batch_inner <= 0) return PMI_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  return a->dtype == PMI_DT_BF16 ? launch<BF16>(*a, s) : launch<F16>(*a, s);
+}
+
+extern "C" int pmi_abi_version(void) { return 1; }

@@ -1,0 +1,174 @@
+// GroupNorm (statistics, coefficient finalisation, fused apply) and LayerNorm (fwd / input-grad)
+// for gfx950.  All HBM-bound: 16-byte vector accesses, fp32 statistics, wave64 reductions.
+#include "common.h"
+#include "../../include/perceptor_hip.h"
+
+namespace {
+
+constexpr int MAXC = 4096;
+
+// ---- GroupNorm statistics: partial (sum, sumsq) per (sample, pixel chunk, group) -------------
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const u16* __restrict__ x, const u16* __restrict__ x1, int C0,
+                                                       float* __restrict__ ws, int HW, int C, int G, int nchunk) {
+  __shared__ float s_sum[MAXC], s_sq[MAXC];
+  const int tid = threadIdx.x, chunk = blockIdx.x, n = blockIdx.y;
+  for (int c = tid; c < C; c += 256) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
+  __syncthreads();
+  const int C8 = C >> 3;
+  const int TPP = C8 < 256 ? C8 : 256;      // threads per pixel
+  const int PPI = 256 / TPP;                // pixels per iteration
+  const int my_p = tid / TPP, my_c = tid - my_p * TPP;
+  const int ppc = (HW + nchunk - 1) / nchunk;
+  const int p0 = chunk * ppc, p1 = min(HW, p0 + ppc);
+  const int C1 = C - C0;
+  if (my_p < PPI) {
+    for (int c8 = my_c; c8 < C8; c8 += TPP) {
+      const bool second = c8 * 8 >= C0;
+      const u16* xb = second ? x1 + (int64_t)n * HW * C1 + (c8 * 8 - C0) : x + (int64_t)n * HW * C0 + c8 * 8;
+      const int ld = second ? C1 : C0;
+      float s[8], q[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+      for (int p = p0 + my_p; p < p1; p += PPI) {
+        float f[8];
+        unpack8<T>(*(const uint4*)(xb + (int64_t)p * ld), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { atomicAdd(&s_sum[c8 * 8 + e], s[e]); atomicAdd(&s_sq[c8 * 8 + e], q[e]); }
+    }
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int g = tid; g < G; g += 256) {
+    float s = 0.f, q = 0.f;
+    for (int j = 0; j < cpg; ++j) { s += s_sum[g * cpg + j]; q += s_sq[g * cpg + j]; }
+    float* o = ws + (((int64_t)n * nchunk + chunk) * G + g) * 2;
+    o[0] = s; o[1] = q;
+  }
+}
+
+// ---- finalize: y = act(x * a[n][c] + b[n][c]) with affine and FiLM folded in -------------------
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ film,
+                                                          int film_ld, float* __restrict__ ca, float* __restrict__ cb,
+                                                          int HW, int C, int G, int nchunk, float eps) {
+  __shared__ float s_mean[256], s_rstd[256];
+  const int tid = threadIdx.x, n = blockIdx.x;
+  const int cpg = C / G;
+  for (int g = tid; g < G; g += 256) {
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nchunk; ++k) {
+      const float* p = ws + (((int64_t)n * nchunk + k) * G + g) * 2;
+      s += p[0]; q += p[1];
+    }
+    const double cnt = (double)HW * cpg;
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mean[g] = (float)mean;
+    s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cpg;
+    float a = s_rstd[g] * (gamma ? gamma[c] : 1.f);
+    float b = (beta ? beta[c] : 0.f) - s_mean[g] * a;
+    if (film) {
+      const float sc = 1.f + film[(int64_t)n * film_ld + c], sh = film[(int64_t)n * film_ld + C + c];
+      a *= sc; b = b * sc + sh;
+    }
+    ca[(int64_t)n * C + c] = a; cb[(int64_t)n * C + c] = b;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void affine_act8(const u16* p, const float* a, const float* b, int act, float* out, float w) {
+  float f[8];
+  unpack8<T>(*(const uint4*)p, f);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) out[e] += w * act_apply(f[e] * a[e] + b[e], act);
+}
+
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const u16* __restrict__ x, const u16* __restrict__ x1, int C0,
+                                                       const float* __restrict__ ca, const float* __restrict__ cb,
+                                                       u16* __restrict__ y, int N, int H, int W, int C, int act) {
+  const int C8 = C >> 3;
+  const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+  const int64_t total = (int64_t)N * Ho * Wo * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int n = (int)(pix / ((int64_t)Ho * Wo));
+    float a[8], b[8], o[8];
+    *(float4*)a = *(const float4*)(ca + (int64_t)n * C + c8 * 8);
+    *(float4*)(a + 4) = *(const float4*)(ca + (int64_t)n * C + c8 * 8 + 4);
+    *(float4*)b = *(const float4*)(cb + (int64_t)n * C + c8 * 8);
+    *(float4*)(b + 4) = *(const float4*)(cb + (int64_t)n * C + c8 * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    const bool second = c8 * 8 >= C0;
+    const u16* src = second ? x1 + (c8 * 8 - C0) : x + c8 * 8;
+    const int ld = second ? C - C0 : C0;
+    if (POOL) {
+      const int rem = (int)(pix - (int64_t)n * Ho * Wo);
+      const int oy = rem / Wo, ox = rem - oy * Wo;
+      const u16* base = src + (((int64_t)n * H + 2 * oy) * W + 2 * ox) * ld;
+      affine_act8<T>(base, a, b, act, o, 0.25f);
+      affine_act8<T>(base + ld, a, b, act, o, 0.25f);
+      affine_act8<T>(base + (int64_t)W * ld, a, b, act, o, 0.25f);
+      affine_act8<T>(base + (int64_t)W * ld + ld, a, b, act, o, 0.25f);
+    } else {
+      affine_act8<T>(src + pix * ld, a, b, act, o, 1.f);
+    }
+    *(uint4*)(y + pix * C + c8 * 8) = pack8<T>(o);
+  }
+}
+
+inline int grid_for(int64_t work) {
+  int64_t b = (work + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 2048 * 4 ? 2048 * 4 : b));
+}
+
+}  // namespace
+
+extern "C" int pmi_gn_stats(const void* x, const void* x1, int C0, float* ws, int N, int HW, int C, int G, int nchunk, int dtype, pmi_stream_t s) {
+  if (!x1) C0 = C;
+  if ((C0 & 7) || C0 <= 0 || C0 > C) return PMI_ERR_ARG;
+  if (!x || !ws || N <= 0 || HW <= 0 || C <= 0 || (C & 7) || C > MAXC || G <= 0 || C % G || nchunk <= 0) return PMI_ERR_ARG;
+  dim3 grid(nchunk, N), block(256);
+  if (dtype == PMI_DT_BF16) hipLaunchKernelGGL(gn_stats_kernel<BF16>, grid, block, 0, (hipStream_t)s, (const u16*)x, (const u16*)x1, C0, ws, HW, C, G, nchunk);
+  else hipLaunchKernelGGL(gn_stats_kernel<F16>, grid, block, 0, (hipStream_t)s, (const u16*)x, (const u16*)x1, C0, ws, HW, C, G, nchunk);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+
+extern "C" int pmi_gn_finalize(const float* ws, const float* gamma, const float* beta, const float* film, int film_ld,
+                               float* coef_a, float* coef_b, int N, int HW, int C, int G, int nchunk, float eps,
+                               pmi_stream_t s) {
+  if (!ws || !coef_a || !coef_b || N <= 0 || C <= 0 || G <= 0 || G > 256 || C % G) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, (hipStream_t)s, ws, gamma, beta, film, film_ld, coef_a,
+                     coef_b, HW, C, G, nchunk, eps);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+
+extern "C" int pmi_gn_apply(const void* x, const void* x1, int C0, const float* coef_a, const float* coef_b, void* y, int N, int H,
+                            int W, int C, int act, int pool, int dtype, pmi_stream_t s) {
+  if (!x1) C0 = C;
+  if ((C0 & 7) || C0 <= 0 || C0 > C) return PMI_ERR_ARG;
+  if (!x || !y || !coef_a || !coef_b || N <= 0 || H <= 0 || W <= 0 || (C & 7)) return PMI_ERR_ARG;
+  if (pool && ((H & 1) || (W & 1))) return PMI_ERR_ARG;
+  const int64_t work = (int64_t)N * (pool ? H / 2 : H) * (pool ? W / 2 : W) * (C / 8);
+  dim3 grid(grid_for(work)), block(256);
+  hipStream_t st = (hipStream_t)s;
+#define GO(TT, PP) hipLaunchKernelGGL((gn_apply_kernel<TT, PP>), grid, block, 0, st, (const u16*)x, (const u16*)x1, C0, coef_a, coef_b, (u16*)y, N, H, W, C, act)
+  if (dtype == PMI_DT_BF16) { if (pool) GO(BF16, true); else GO(BF16, false); }
+  else { if (pool) GO(F16, true); else GO(F16, false); }
+#undef GO
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}

@@ -1,0 +1,279 @@
+"""HIP execution engine for the ADM UNet (ε-prediction) — replaces UNetModel.forward.
+
+Mirrors perceptor/models/guided_diffusion/unet.py:626-654 (forward), :232-252
+(ResBlock), :294-300 (AttentionBlock) and the constructor loops :471-601, but runs
+NHWC 16-bit activations through libperceptor_hip.so:
+
+  * every conv3x3 / conv1x1 / linear is one pmi_igemm launch (MFMA implicit GEMM) with
+    bias, per-sample bias, residual add, nearest-up gather and skip-concat (two source
+    pointers) fused, so th.cat / F.interpolate / "+ skip" never touch HBM on their own;
+  * GroupNorm32+SiLU(+FiLM)(+AvgPool) is stats -> finalize -> apply, fp32 statistics;
+  * all 49 emb_layers linears run as ONE GEMM per step (their weights are concatenated);
+  * attention with 64-channel heads runs the fused flash kernel.
+
+State-dict keys are the reference's, so a real checkpoint loads as is.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .. import _hip
+from .._hip import ACT_NONE, ACT_SILU, call, ptr
+from . import ops
+from .ops import PackedLinear
+
+
+@dataclass(frozen=True)
+class AdmConfig:
+    """Resolved hyper-parameters (script_util.py:130-184)."""
+    image_size: int
+    model_channels: int
+    num_res_blocks: int
+    channel_mult: Tuple[float, ...]
+    attention_ds: Tuple[int, ...]
+    num_heads: int = 1
+    num_head_channels: int = -1
+    num_heads_upsample: int = -1
+    use_scale_shift_norm: bool = False
+    resblock_updown: bool = False
+    use_new_attention_order: bool = False
+    in_channels: int = 3
+    out_channels: int = 6
+    conv_resample: bool = True
+
+
+_DEFAULT_MULT = {512: (0.5, 1, 1, 2, 2, 4, 4), 256: (1, 1, 2, 2, 4, 4), 128: (1, 1, 2, 3, 4), 64: (1, 2, 3, 4)}
+
+
+def openimages_config() -> AdmConfig:   # create_models.py:8-33
+    return AdmConfig(512, 256, 2, _DEFAULT_MULT[512], (16, 32, 64), num_head_channels=64,
+                     use_scale_shift_norm=True, resblock_updown=True)
+
+
+def pixelart_config() -> AdmConfig:     # create_models.py:36-62
+    return AdmConfig(256, 128, 2, _DEFAULT_MULT[256], (16,), num_heads=1)
+
+
+class _Res:
+    def __init__(self, prefix, cin, cout, up=False, down=False):
+        self.p, self.cin, self.cout, self.up, self.down = prefix, cin, cout, up, down
+        self.emb_off = 0
+
+
+class _Attn:
+    def __init__(self, prefix, c, heads):
+        self.p, self.c, self.heads = prefix, c, heads
+
+
+class _Resample:
+    def __init__(self, prefix, c, up):
+        self.p, self.c, self.up = prefix, c, up
+
+
+def build_plan(cfg: AdmConfig):
+    """Layer descriptors in execution order + parameter shapes (names as in the reference)."""
+    mc = cfg.model_channels
+
+    def heads(c, upsample=False):
+        if cfg.num_head_channels != -1:
+            return c // cfg.num_head_channels
+        if upsample and cfg.num_heads_upsample != -1:
+            return cfg.num_heads_upsample
+        return cfg.num_heads
+
+    ch = int(cfg.channel_mult[0] * mc)
+    inp: List[list] = [[("conv0", "input_blocks.0.0", cfg.in_channels, ch)]]
+    skip_ch = [ch]
+    ds = 1
+    for level, mult in enumerate(cfg.channel_mult):
+        for _ in range(cfg.num_res_blocks):
+            i = len(inp)
+            cout = int(mult * mc)
+            layers = [_Res(f"input_blocks.{i}.0", ch, cout)]
+            ch = cout
+            if ds in cfg.attention_ds:
+                layers.append(_Attn(f"input_blocks.{i}.1", ch, heads(ch)))
+            inp.append(layers)
+            skip_ch.append(ch)
+        if level != len(cfg.channel_mult) - 1:
+            i = len(inp)
+            if cfg.resblock_updown:
+                inp.append([_Res(f"input_blocks.{i}.0", ch, ch, down=True)])
+            else:
+                inp.append([_Resample(f"input_blocks.{i}.0", ch, up=False)])
+            skip_ch.append(ch)
+            ds *= 2
+    mid = [_Res("middle_block.0", ch, ch), _Attn("middle_block.1", ch, heads(ch)), _Res("middle_block.2", ch, ch)]
+    out: List[list] = []
+    for level, mult in list(enumerate(cfg.channel_mult))[::-1]:
+        for i in range(cfg.num_res_blocks + 1):
+            j = len(out)
+            ich = skip_ch.pop()
+            cout = int(mc * mult)
+            layers = [_Res(f"output_blocks.{j}.0", ch + ich, cout)]
+            ch = cout
+            k = 1
+            if ds in cfg.attention_ds:
+                layers.append(_Attn(f"output_blocks.{j}.{k}", ch, heads(ch, True)))
+                k += 1
+            if level and i == cfg.num_res_blocks:
+                if cfg.resblock_updown:
+                    layers.append(_Res(f"output_blocks.{j}.{k}", ch, ch, up=True))
+                else:
+                    layers.append(_Resample(f"output_blocks.{j}.{k}", ch, up=True))
+                ds //= 2
+            out.append(layers)
+    return inp, mid, out, ch
+
+
+def state_dict_shapes(cfg: AdmConfig) -> Dict[str, Tuple[int, ...]]:
+    mc, ted = cfg.model_channels, 4 * cfg.model_channels
+    inp, mid, out, ch_last = build_plan(cfg)
+    S: Dict[str, Tuple[int, ...]] = {
+        "time_embed.0.weight": (ted, mc), "time_embed.0.bias": (ted,),
+        "time_embed.2.weight": (ted, ted), "time_embed.2.bias": (ted,)}
+    for layers in inp + [mid] + out:
+        for l in layers:
+            if isinstance(l, tuple):
+                S[l[1] + ".weight"] = (l[3], l[2], 3, 3); S[l[1] + ".bias"] = (l[3],)
+            elif isinstance(l, _Res):
+                p = l.p
+                S[p + ".in_layers.0.weight"] = (l.cin,); S[p + ".in_layers.0.bias"] = (l.cin,)
+                S[p + ".in_layers.2.weight"] = (l.cout, l.cin, 3, 3); S[p + ".in_layers.2.bias"] = (l.cout,)
+                e = 2 * l.cout if cfg.use_scale_shift_norm else l.cout
+                S[p + ".emb_layers.1.weight"] = (e, ted); S[p + ".emb_layers.1.bias"] = (e,)
+                S[p + ".out_layers.0.weight"] = (l.cout,); S[p + ".out_layers.0.bias"] = (l.cout,)
+                S[p + ".out_layers.3.weight"] = (l.cout, l.cout, 3, 3); S[p + ".out_layers.3.bias"] = (l.cout,)
+                if l.cin != l.cout:
+                    S[p + ".skip_connection.weight"] = (l.cout, l.cin, 1, 1); S[p + ".skip_connection.bias"] = (l.cout,)
+            elif isinstance(l, _Attn):
+                p = l.p
+                S[p + ".norm.weight"] = (l.c,); S[p + ".norm.bias"] = (l.c,)
+                S[p + ".qkv.weight"] = (3 * l.c, l.c, 1); S[p + ".qkv.bias"] = (3 * l.c,)
+                S[p + ".proj_out.weight"] = (l.c, l.c, 1); S[p + ".proj_out.bias"] = (l.c,)
+            elif isinstance(l, _Resample) and cfg.conv_resample:
+                n = l.p + (".conv" if l.up else ".op")
+                S[n + ".weight"] = (l.c, l.c, 3, 3); S[n + ".bias"] = (l.c,)
+    S["out.0.weight"] = (ch_last,); S["out.0.bias"] = (ch_last,)
+    S["out.2.weight"] = (cfg.out_channels, int(cfg.channel_mult[0] * mc), 3, 3); S["out.2.bias"] = (cfg.out_channels,)
+    return S
+
+
+class AdmEngine:
+    def __init__(self, cfg: AdmConfig, state_dict: Dict[str, torch.Tensor], device, dtype="bf16"):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.dt = _hip.dtype_code(dtype)
+        _hip.lib()
+        sd, dev, dt = state_dict, self.device, self.dt
+        self.inp, self.mid, self.out, self.ch_last = build_plan(cfg)
+        f32 = lambda k: sd[k].detach().float().to(dev).contiguous()
+        lin = lambda k, **kw: PackedLinear(sd[k + ".weight"], sd.get(k + ".bias"), dt, dev, **kw)
+        self.w: Dict[str, object] = {}
+        self.te0, self.te2 = lin("time_embed.0"), lin("time_embed.2")
+        emb_w, emb_b, off = [], [], 0
+        for layers in self.inp + [self.mid] + self.out:
+            for l in layers:
+                if isinstance(l, tuple):
+                    self.w[l[1]] = lin(l[1], cin_pad=8)
+                elif isinstance(l, _Res):
+                    p = l.p
+                    self.w[p + ".gn1"] = (f32(p + ".in_layers.0.weight"), f32(p + ".in_layers.0.bias"))
+                    self.w[p + ".conv1"] = lin(p + ".in_layers.2")
+                    self.w[p + ".gn2"] = (f32(p + ".out_layers.0.weight"), f32(p + ".out_layers.0.bias"))
+                    self.w[p + ".conv2"] = lin(p + ".out_layers.3")
+                    if l.cin != l.cout:
+                        self.w[p + ".skip"] = lin(p + ".skip_connection")
+                    l.emb_off = off
+                    emb_w.append(sd[p + ".emb_layers.1.weight"].float()); emb_b.append(sd[p + ".emb_layers.1.bias"].float())
+                    off += emb_w[-1].shape[0]
+                elif isinstance(l, _Attn):
+                    p = l.p
+                    self.w[p + ".gn"] = (f32(p + ".norm.weight"), f32(p + ".norm.bias"))
+                    self.w[p + ".qkv"] = lin(p + ".qkv")
+                    self.w[p + ".proj"] = lin(p + ".proj_out")
+                elif isinstance(l, _Resample) and cfg.conv_resample:
+                    self.w[l.p] = lin(l.p + (".conv" if l.up else ".op"))
+        self.emb_all = PackedLinear(torch.cat(emb_w, 0), torch.cat(emb_b, 0), dt, dev)
+        self.gn_out = (f32("out.0.weight"), f32("out.0.bias"))
+        self.conv_out = lin("out.2")
+
+    # ---- blocks ----------------------------------------------------------------------------------
+    def _res(self, l: _Res, x, x1, emb):
+        cfg, dt, w = self.cfg, self.dt, self.w
+        g1, b1 = w[l.p + ".gn1"]
+        h = ops.group_norm(x, g1, b1, 32, dt, x1=x1, act=ACT_SILU, pool=l.down)
+        ecols = 2 * l.cout if cfg.use_scale_shift_norm else l.cout
+        e = emb[:, l.emb_off:l.emb_off + ecols]
+        skip, skip1 = x, x1
+        if l.down:
+            skip = ops.avgpool2(x, dt)
+        h = ops.igemm(h, w[l.p + ".conv1"], up=l.up, nbias=None if cfg.use_scale_shift_norm else e)
+        g2, b2 = w[l.p + ".gn2"]
+        if cfg.use_scale_shift_norm:
+            h = ops.group_norm(h, g2, b2, 32, dt, film=e, film_ld=emb.stride(0), act=ACT_SILU)
+        else:
+            h = ops.group_norm(h, g2, b2, 32, dt, act=ACT_SILU)
+        if l.cin != l.cout:
+            skip = ops.igemm(skip, w[l.p + ".skip"], a1=skip1)
+        return ops.igemm(h, w[l.p + ".conv2"], residual=skip, res_up=l.up)
+
+    def _attn(self, l: _Attn, x):
+        dt, w = self.dt, self.w
+        n, hh, ww, c = x.shape
+        g, b = w[l.p + ".gn"]
+        hn = ops.group_norm(x, g, b, 32, dt)
+        qkv = ops.igemm(hn.view(n * hh * ww, c), w[l.p + ".qkv"])
+        a = ops.attention(qkv.view(n, hh * ww, 3 * c), l.heads, 1 if self.cfg.use_new_attention_order else 0, dt)
+        out = ops.igemm(a.view(n * hh * ww, c), w[l.p + ".proj"], residual=x.view(n * hh * ww, c))
+        return out.view(n, hh, ww, c)
+
+    def _run(self, layers, h, h1, emb):
+        for l in layers:
+            if isinstance(l, tuple):
+                h = ops.igemm(h, self.w[l[1]])
+            elif isinstance(l, _Res):
+                h = self._res(l, h, h1, emb)
+            elif isinstance(l, _Attn):
+                h = self._attn(l, h)
+            elif isinstance(l, _Resample):
+                if self.cfg.conv_resample:
+                    h = ops.igemm(h, self.w[l.p], up=l.up, stride=1 if l.up else 2)
+                else:
+                    raise NotImplementedError("conv_resample=False is not used by the shipped configs")
+            h1 = None
+        return h
+
+    @torch.no_grad()
+    def forward(self, images: torch.Tensor, timesteps: torch.Tensor, out_channels: Optional[int] = None) -> torch.Tensor:
+        """images: NCHW fp32 in [0,1] (encoded to x = 2*img-1 on the fly); returns NCHW fp32 model output."""
+        cfg, dt, dev = self.cfg, self.dt, self.device
+        if not images.is_cuda:
+            raise RuntimeError("AdmEngine runs on a HIP device only (no CPU fallback)")
+        images = images.float().contiguous()
+        n, _, hh, ww = images.shape
+        t = timesteps.to(device=dev, dtype=torch.float32).contiguous()
+        tdt = _hip.TORCH_DTYPE[dt]
+        temb = torch.empty((n, cfg.model_channels), dtype=tdt, device=dev)
+        call("pmi_timestep_embedding", ptr(t), ptr(temb), n, cfg.model_channels, 10000.0, dt)
+        e = ops.igemm(temb, self.te0, act=ACT_SILU)
+        e = ops.igemm(e, self.te2, act=ACT_SILU)            # = SiLU(emb): the only form the ResBlocks consume
+        emb = ops.igemm(e, self.emb_all, out_f32=True)       # [N, sum of all emb_layers outputs]
+        x = torch.empty((n, hh, ww, 8), dtype=tdt, device=dev)
+        call("pmi_prep_input", ptr(images), None, 0, ptr(x), n, hh, ww, 8, dt)
+        h, hs = x, []
+        for layers in self.inp:
+            h = self._run(layers, h, None, emb)
+            hs.append(h)
+        h = self._run(self.mid, h, None, emb)
+        for layers in self.out:
+            h = self._run(layers, h, hs.pop(), emb)
+        g, b = self.gn_out
+        h = ops.group_norm(h, g, b, 32, dt, act=ACT_SILU)
+        y = ops.igemm(h, self.conv_out, out_f32=True)
+        co = out_channels or cfg.out_channels
+        out = torch.empty((n, co, hh, ww), dtype=torch.float32, device=dev)
+        call("pmi_finish_output", ptr(y), y.shape[-1], ptr(out), n, hh, ww, co)
+        return out

@@ -1,0 +1,182 @@
+"""Tensor-level wrappers over the C ABI (perceptor_amd/_hip.py).
+
+Activations are NHWC 16-bit torch tensors ([N, H, W, C] or [M, C]); every
+function launches hand-written HIP kernels on the current stream.  torch is
+used only for device memory.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from .. import _hip
+from .._hip import ACT_NONE, IgemmArgs, call, ptr
+
+
+def _empty(shape, dtype, device):
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
+class PackedLinear:
+    """Weights packed for pmi_igemm: B[Npad][K] 16-bit with k = tap*Cin + c, fp32 bias."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], dt: int, device, cin_pad: Optional[int] = None):
+        w = weight.detach().float()
+        if w.ndim == 3:   # Conv1d k=1
+            w = w[..., 0]
+        if w.ndim == 2:
+            w = w[:, :, None, None]
+        cout, cin, kh, kw = w.shape
+        self.cout, self.cin, self.taps = cout, cin, kh * kw
+        self.cin_p = cin_pad if cin_pad is not None else (cin + 7) // 8 * 8
+        self.n_p = (cout + 3) // 4 * 4
+        packed = torch.zeros(self.n_p, kh * kw, self.cin_p, dtype=torch.float32)
+        packed[:cout, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+        self.w = packed.reshape(self.n_p, -1).to(device=device, dtype=_hip.TORCH_DTYPE[dt]).contiguous()
+        self.b = None
+        if bias is not None:
+            b = torch.zeros(self.n_p, dtype=torch.float32)
+            b[:cout] = bias.detach().float()
+            self.b = b.to(device)
+        self.dt = dt
+
+    @property
+    def K(self):
+        return self.taps * self.cin_p
+
+
+def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+          act: int = ACT_NONE, up: bool = False, stride: int = 1, res_up: bool = False, nbias: Optional[torch.Tensor] = None,
+          out_f32: bool = False, out: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+    """Convolution (a0 is [N,H,W,C]) or linear (a0 is [M,C]) through pmi_igemm."""
+    dt = lin.dt
+    conv = a0.ndim == 4
+    c0 = a0.shape[-1]
+    c1 = a1.shape[-1] if a1 is not None else 0
+    assert c0 + c1 == lin.cin_p, (c0, c1, lin.cin_p)
+    a = IgemmArgs()
+    if conv:
+        n, hin, win, _ = a0.shape
+        hv, wv = (hin * 2, win * 2) if up else (hin, win)
+        h, w = hv // stride, wv // stride
+        m = n * h * w
+        a.H, a.W, a.Hin, a.Win = h, w, hin, win
+        a.hw = h * w
+        oshape = (n, h, w, lin.n_p)
+    else:
+        assert lin.taps == 1 and not up and stride == 1
+        m = a0.shape[0]
+        a.hw = 1
+        oshape = (m, lin.n_p)
+    if out is None:
+        out = _empty(oshape, torch.float32 if out_f32 else _hip.TORCH_DTYPE[dt], a0.device)
+    a.A0, a.A1, a.B = ptr(a0), ptr(a1), ptr(lin.w)
+    a.bias, a.nbias, a.R, a.D = ptr(lin.b), ptr(nbias), ptr(residual), ptr(out)
+    a.M, a.N, a.K = m, lin.n_p, lin.K
+    a.C0, a.C1 = c0, c1
+    a.lda0, a.lda1 = a0.stride(-2), (a1.stride(-2) if a1 is not None else 0)
+    a.ldb, a.ldd = lin.K, out.stride(-2)
+    a.ldr = residual.stride(-2) if residual is not None else 0
+    a.taps, a.stride, a.up, a.res_up, a.act = lin.taps, stride, int(up), int(res_up), act
+    a.out_f32 = int(out.dtype == torch.float32)
+    a.res_f32 = int(residual is not None and residual.dtype == torch.float32)
+    a.alpha = alpha
+    a.ldnb = nbias.stride(0) if nbias is not None else 0
+    a.batch, a.batch_inner = 1, 1
+    a.dtype = dt
+    call("pmi_igemm", C.byref(a))
+    return out
+
+
+def bgemm(A: torch.Tensor, B: torch.Tensor, D: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldb: int, ldd: int,
+          batch: int, batch_inner: int, sA, sB, sD, dt: int, alpha: float = 1.0, a_off: int = 0, b_off: int = 0, d_off: int = 0):
+    """Batched D[z] = alpha * A[z] @ B[z]^T with two-level (outer, inner) element strides."""
+    a = IgemmArgs()
+    es = A.element_size()
+    a.A0 = A.data_ptr() + a_off * es
+    a.B = B.data_ptr() + b_off * B.element_size()
+    a.D = D.data_ptr() + d_off * D.element_size()
+    a.M, a.N, a.K, a.C0, a.C1 = M, N, K, K, 0
+    a.lda0, a.ldb, a.ldd = lda, ldb, ldd
+    a.taps, a.stride, a.hw, a.alpha = 1, 1, 1, alpha
+    a.out_f32 = int(D.dtype == torch.float32)
+    a.batch, a.batch_inner = batch, batch_inner
+    a.sA_o, a.sA_i = sA
+    a.sB_o, a.sB_i = sB
+    a.sD_o, a.sD_i = sD
+    a.dtype = dt
+    call("pmi_igemm", C.byref(a))
+    return D
+
+
+def group_norm(x: torch.Tensor, gamma, beta, groups: int, dt: int, *, x1: Optional[torch.Tensor] = None,
+               film: Optional[torch.Tensor] = None, film_ld: int = 0,
+               act: int = ACT_NONE, pool: bool = False, eps: float = 1e-5) -> torch.Tensor:
+    """GroupNorm over the channel-concat of x (and x1) -> act(norm * gamma + beta [FiLM]) [-> 2x2 avg pool]."""
+    n, h, w, c0 = x.shape
+    c = c0 + (x1.shape[-1] if x1 is not None else 0)
+    hw = h * w
+    nchunk = max(1, min(hw // 64, (1024 + n - 1) // n))
+    dev = x.device
+    ws = _empty((n, nchunk, groups, 2), torch.float32, dev)
+    ca = _empty((n, c), torch.float32, dev)
+    cb = _empty((n, c), torch.float32, dev)
+    call("pmi_gn_stats", ptr(x), ptr(x1), c0, ptr(ws), n, hw, c, groups, nchunk, dt)
+    call("pmi_gn_finalize", ptr(ws), ptr(gamma), ptr(beta), ptr(film), film_ld, ptr(ca), ptr(cb), n, hw, c, groups, nchunk, eps)
+    y = _empty((n, h // 2, w // 2, c) if pool else (n, h, w, c), x.dtype, dev)
+    call("pmi_gn_apply", ptr(x), ptr(x1), c0, ptr(ca), ptr(cb), ptr(y), n, h, w, c, act, int(pool), dt)
+    return y
+
+
+def avgpool2(x: torch.Tensor, dt: int) -> torch.Tensor:
+    n, h, w, c = x.shape
+    y = _empty((n, h // 2, w // 2, c), x.dtype, x.device)
+    call("pmi_avgpool2", ptr(x), ptr(y), n, h, w, c, dt)
+    return y
+
+
+def upsample_bilinear2(x: torch.Tensor, dt: int) -> torch.Tensor:
+    n, h, w, c = x.shape
+    y = _empty((n, h * 2, w * 2, c), x.dtype, x.device)
+    call("pmi_upsample_bilinear2", ptr(x), ptr(y), n, h, w, c, dt)
+    return y
+
+
+def attention(qkv: torch.Tensor, heads: int, order: int, dt: int) -> torch.Tensor:
+    """Self-attention over tokens.  qkv: [N, T, 3C] 16-bit -> [N, T, C].
+
+    order 0: channels = (head, {q,k,v}, d) (unet.py:332-348); order 1: ({q,k,v}, head, d).
+    Head dim 64 runs the fused flash kernel; other head dims use batched MFMA GEMMs + softmax.
+    """
+    n, t, c3 = qkv.shape
+    c = c3 // 3
+    d = c // heads
+    dev = qkv.device
+    out = _empty((n, t, c), qkv.dtype, dev)
+    scale = float(d) ** -0.5
+    if d == 64:
+        tp = (t + 31) // 32 * 32
+        q = _empty((n * heads, tp, 64), qkv.dtype, dev)
+        k = _empty((n * heads, tp, 64), qkv.dtype, dev)
+        vt = _empty((n * heads, 64, tp), qkv.dtype, dev)
+        call("pmi_qkv_split", ptr(qkv), ptr(q), ptr(k), ptr(vt), n, t, heads, order, dt)
+        call("pmi_attn_d64", ptr(q), ptr(k), ptr(vt), ptr(out), n, t, heads, scale, dt)
+        return out
+    assert d % 8 == 0, "head dim must be a multiple of 8"
+    tp = (t + 7) // 8 * 8
+    if order == 0:
+        qo, ko, vo, hs = 0, d, 2 * d, 3 * d
+    else:
+        qo, ko, vo, hs = 0, c, 2 * c, d
+    s = _empty((n * heads, t, tp), torch.float32, dev)
+    bgemm(qkv, qkv, s, M=t, N=t, K=d, lda=c3, ldb=c3, ldd=tp, batch=n * heads, batch_inner=heads,
+          sA=(t * c3, hs), sB=(t * c3, hs), sD=(heads * t * tp, t * tp), dt=dt, a_off=qo, b_off=ko)
+    p = _empty((n * heads, t, tp), qkv.dtype, dev)
+    call("pmi_softmax_fwd", ptr(s), ptr(p), n * heads * t, t, tp, tp, scale, dt)
+    vt = _empty((n * heads, d, tp), qkv.dtype, dev)
+    call("pmi_transpose_16", qkv.data_ptr() + vo * qkv.element_size(), ptr(vt), t, d, c3, t * c3, hs, heads, n * heads)
+    bgemm(p, vt, out, M=t, N=d, K=tp, lda=tp, ldb=tp, ldd=c, batch=n * heads, batch_inner=heads,
+          sA=(heads * t * tp, t * tp), sB=(heads * d * tp, d * tp), sD=(t * c, d), dt=dt)
+    return out
