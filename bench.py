@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py — denoising steps/s of the guided-diffusion sampling hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json metric "denoising steps/sec (UNet+CLIP-grad) at 512x512 batch 8"):
+  config c5 (default) = configs[4] per-GPU share: GuidedDiffusion "standard" UNet @512x512,
+  batch 8 per GPU (weak scaling: N GPUs sample 8N independent chains), OpenCLIP ViT-L/14
+  guidance gradient, bf16 MFMA, synthetic weights/inputs.
+  One step = UNet eps-prediction -> denoised images -> CLIP loss forward+backward to the image
+  -> Predictions.guided -> Predictions.step (DDIM).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) incl. "roofline" and "cpu_baseline".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0}   # dense MFMA peak, MI355X_MICROARCH.md (never the 2:1-sparse figure)
+
+# forward GFLOP / sample (torch flop counter on the reference modules)
+UNET_GFLOP = {"standard": {512: 3964.7, 256: 989.0}, "pixelart": {256: 497.5}}
+CLIP_FWD_GFLOP = {"ViT-B-32": 8.82, "ViT-B-16": 35.13, "ViT-L-14": 162.03, "ViT-H-14": 334.59}
+
+CONFIGS = {
+    # name: (model, resolution, batch per GPU, clip arch)
+    "c5": ("standard", 512, 8, "ViT-L-14"),
+    "c2": ("standard", 256, 4, None),
+    "c5-noclip": ("standard", 512, 8, None),
+    "smoke": ("pixelart", 64, 2, None),
+}
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--config", default="c5", choices=sorted(CONFIGS))
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-kernel-events", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(model_name, res, clip_arch, seed=0):
+    """Oracle (CPU fp32 port of the reference path) timed on a bounded sample: batch 1 at 128x128 for the
+    UNet (+ batch-1 CLIP fwd+bwd), scaled by the FLOP ratio to the benchmark's batch/resolution."""
+    from oracle import adm_unet
+    from perceptor_amd.utils.synth import seeded_noise, synth_state_dict
+    cores = torch.get_num_threads()
+    cfg = adm_unet.openimages_config() if model_name == "standard" else adm_unet.pixelart_config()
+    sd = synth_state_dict(adm_unet.state_dict_shapes(cfg), seed)
+    sres = 128 if res >= 128 else res
+    x = seeded_noise((1, 3, sres, sres), 1234)
+    t = torch.tensor([500])
+    adm_unet.adm_unet_forward(sd, cfg, x, t)              # warm-up
+    t0 = time.time()
+    reps = 2
+    for _ in range(reps):
+        adm_unet.adm_unet_forward(sd, cfg, x, t)
+    t_unet = (time.time() - t0) / reps
+    return t_unet, sres, cores
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from perceptor_amd import models
+    from perceptor_amd.engine import ops
+    from perceptor_amd.utils.synth import seeded_noise
+
+    model_name, res, nb, clip_arch = CONFIGS[a.config]
+    model = models.GuidedDiffusion(model_name, dtype=a.dtype).to(dev)
+    clip_loss = None
+    if clip_arch is not None:
+        from perceptor_amd import losses
+        clip_loss = losses.OpenCLIP(clip_arch, "synthetic", dtype="bf16").to(dev)
+        tg = torch.nn.functional.normalize(seeded_noise((2, clip_loss.model.output_dim), 7))
+        clip_loss.add_encodings_(tg.to(dev))
+    # one global noise batch, sliced per rank: results do not depend on the number of GPUs
+    noise = seeded_noise((nb * world, 3, res, res), 1234)[rank * nb:(rank + 1) * nb]
+    images = (noise * 0.5 + 0.5).to(dev)
+    n_sched = max(a.steps + a.warmup + 1, 50)
+    sched = model.schedule_indices(n_steps=n_sched, rho=7.0)
+
+    def one_step(images, i):
+        fi, ti = sched[i % len(sched)]
+        pred = model.predictions(images, fi)
+        if clip_loss is not None:
+            _, grad = clip_loss.loss_and_grad(pred.denoised_images, n_total=nb * world)
+            pred = pred.guided(grad, guidance_scale=0.5, clamp_value=1e-6)
+        return pred.step(ti)
+
+    for i in range(a.warmup):
+        images = one_step(images, i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not a.no_kernel_events:
+        ops.KERNEL_EVENTS = []
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ev[i][0].record()
+        images = one_step(images, a.warmup + i)
+        ev[i][1].record()
+    if dist is not None:
+        gathered = [torch.empty_like(images) for _ in range(world)]
+        dist.all_gather(gathered, images)       # RCCL over xGMI: the only collective of the job
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    finite = bool(torch.isfinite(images).all().item())
+
+    if rank == 0:
+        step_ms_dev = sum(s.elapsed_time(e) for s, e in ev) / a.steps
+        gflop_sample = UNET_GFLOP[model_name][res] + (2 * CLIP_FWD_GFLOP[clip_arch] if clip_arch else 0.0)
+        tflop_step = gflop_sample * nb / 1e3
+        achieved = tflop_step / (step_ms_dev / 1e3)
+        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_TFLOPS[a.dtype], 4), "traffic": None,
+                "scope": "whole step (UNet fwd + CLIP fwd+bwd + update), algorithmic FLOP / HIP-event step time"}
+        if kernel_events:
+            tot_ms = sum(s.elapsed_time(e) for (s, e, _) in kernel_events)
+            tot_fl = sum(f for (_, _, f) in kernel_events)
+            roof["kernel"] = {"name": "igemm_kernel (conv3x3 implicit GEMM, MFMA)", "launches": len(kernel_events),
+                              "avg_ms": round(tot_ms / len(kernel_events), 4),
+                              "achieved": round(tot_fl / 1e12 / (tot_ms / 1e3), 2),
+                              "frac": round(tot_fl / 1e12 / (tot_ms / 1e3) / PEAK_TFLOPS[a.dtype], 4),
+                              "share_of_step": round(tot_ms / a.steps / step_ms_dev, 3)}
+        out = {
+            "metric": "denoising steps/sec (UNet+CLIP-grad) at 512x512 batch 8" if a.config == "c5" else f"denoising steps/sec ({a.config})",
+            "value": round(a.steps * world / elapsed, 4) if False else round(a.steps / elapsed * world, 4),
+            "unit": "steps/s (batch-8 steps summed over GPUs)",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"GuidedDiffusion '{model_name}' UNet {res}x{res}, batch {nb}/GPU"
+                                   + (f" + OpenCLIP {clip_arch} guidance (fwd+bwd to image)" if clip_arch else " (no CLIP)")
+                                   + ", DDIM eta=0, synthetic weights", "name": a.config,
+                       "global_batch": nb * world, "parallelism": f"replica-sharded chains x{world}"},
+            "outputs_finite": finite,
+            "roofline": roof,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            t_unet, sres, cores = cpu_baseline(model_name, res, clip_arch)
+            scale = (res / sres) ** 2 * nb
+            sec_step = t_unet * scale * (gflop_sample / UNET_GFLOP[model_name][res])
+            out["cpu_baseline"] = {"value": round(1.0 / sec_step, 6), "unit": "steps/s (batch-8 steps)", "cores": cores, "kind": "port",
+                                   "sample": f"oracle UNet fwd batch 1 @{sres}x{sres} = {t_unet:.2f}s, scaled x{scale:.0f} by pixel*batch"
+                                             f" and x{gflop_sample / UNET_GFLOP[model_name][res]:.3f} for the CLIP FLOP share"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -111,13 +111,19 @@ int pmi_ddim_v_step(const float* img, const float* v, const float* a_from, const
 int pmi_guided_update(const float* pred, const float* grad, const float* s_from, float scale, float clamp_value,
                       float* out, int N, int64_t chw, pmi_stream_t s);
 
+/* remaining Predictions algebra (predictions.py:101-145,174-179 ; velocity_diffusion/predictions.py:107-200):
+ * out = ca[n]*a + cb[n]*b + cc[n] with per-sample coefficients (b, cb, cc optional); clamp with per-sample bounds */
+int pmi_lincomb2(const float* a, const float* b, const float* ca, const float* cb, const float* cc, float* out, int N,
+                 int64_t chw, pmi_stream_t s);
+int pmi_clamp(const float* a, const float* lo, const float* hi, float* out, int N, int64_t chw, pmi_stream_t s);
+
 /* ---- CLIP guidance path (forward + input-gradient) ---------------------------------------
  * ViT arithmetic: open-clip-torch 2.0.2 visual tower == OpenAI-CLIP VisionTransformer, in-tree copy
  * ruclip/model.py:11-131; wrapper models/open_clip.py:109-123; loss losses/clip/clip.py:89-99.
  * The linear layers (and their dX = dY * W input gradients) run on pmi_igemm; these are the
  * memory-bound pieces between them.                                                           */
 /* LayerNorm (ruclip/model.py:11-17): fp32 rows -> 16-bit and/or fp32; mean_rstd = [mean[M] | rstd[M]] saved for bwd */
-int pmi_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y16, float* y32, float* mean_rstd,
+int pmi_layernorm_fwd(const float* x, int ld_x, const float* gamma, const float* beta, void* y16, float* y32, float* mean_rstd,
                       int M, int D, float eps, int dtype, pmi_stream_t s);
 /* input gradient; dy row r (stride dy_ld) belongs to row r*row_stride of x/gres/outputs; out = dx + gres */
 int pmi_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean_rstd, const float* gres,
@@ -135,7 +141,9 @@ int pmi_resize_apply(const float* in, float* out, const int* idx, const float* w
                      int taps, int r0, int r1, pmi_stream_t s);
 /* Normalize (models/open_clip.py:78-81) + patch conv as im2col (ruclip/model.py:84-90,105): col[N*g*g][Kp] 16-bit */
 int pmi_patchify(const float* img, const float* mean, const float* stdv, void* col, int N, int R, int P, int Kp, int r0, int dtype, pmi_stream_t s);
-int pmi_unpatchify(const float* dcol, const float* stdv, float* dimg, int N, int R, int P, int Kp, int r0, int r1, pmi_stream_t s);
+int pmi_unpatchify(const float* dcol, const float* stdv, float* dimg, int N, int R, int P, int Kp, float mul, pmi_stream_t s);
+int pmi_act_fwd(const void* in, void* out, int64_t n, int act, int dtype, pmi_stream_t s);   /* QuickGELU / GELU (ruclip/model.py:20-23) */
+int pmi_l2norm_rows(const float* x, float* y, int M, int D, pmi_stream_t s);                 /* F.normalize, models/open_clip.py:120-121 */
 int pmi_vit_assemble(const float* emb, const float* cls, const float* pos, float* x, int N, int T, int D, int r0, pmi_stream_t s);
 /* losses/clip/clip.py:89-99 (+ F.normalize of models/open_clip.py:120-121): loss = mult * sum_{n,k} w_k 2 asin(|e_n-t_k|/2)^2 / (n_total*K);
  * demb = gscale * dloss/demb (emb un-normalised).  n_total = global batch (>= N) so a sharded batch keeps the global mean. */

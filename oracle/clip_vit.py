@@ -114,7 +114,8 @@ def resize_matrix(in_sz: int, out_sz: int, method: str) -> torch.Tensor:
         cur_support, f = support, fn
     left = (grid - cur_support / 2 - eps).ceil().long()
     fov = left[:, None] + torch.arange(ceil(cur_support - eps))
-    w = f(grid[:, None] - fov)
+    pad0 = -int(fov[0, 0])           # calc_pad_sz shifts both by the left pad before the kernel is evaluated
+    w = f((grid + pad0)[:, None] - (fov + pad0))
     s = w.sum(1, keepdim=True)
     s[s == 0] = 1
     w = w / s

@@ -64,16 +64,20 @@ _PROTOS = {
     "pmi_ddim_eps_step": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _P],),
     "pmi_ddim_v_step": ([_P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _P],),
     "pmi_guided_update": ([_P, _P, _P, _F, _F, _P, _I, _L, _P],),
+    "pmi_lincomb2": ([_P, _P, _P, _P, _P, _P, _I, _L, _P],),
+    "pmi_clamp": ([_P, _P, _P, _P, _I, _L, _P],),
     # CLIP path (clip.hip)
-    "pmi_layernorm_fwd": ([_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],),
-    "pmi_layernorm_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],),
+    "pmi_layernorm_fwd": ([_P, _I, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],),
+    "pmi_layernorm_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],),
     "pmi_softmax_fwd": ([_P, _P, _I, _I, _I, _I, _F, _I, _P],),
     "pmi_softmax_bwd": ([_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],),
     "pmi_transpose_16": ([_P, _P, _I, _I, _I, _L, _L, _I, _I, _P],),
     "pmi_act_bwd": ([_P, _P, _P, _L, _I, _I, _P],),
     "pmi_resize_apply": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],),
     "pmi_patchify": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],),
-    "pmi_unpatchify": ([_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],),
+    "pmi_unpatchify": ([_P, _P, _P, _I, _I, _I, _I, _F, _P],),
+    "pmi_act_fwd": ([_P, _P, _L, _I, _I, _P],),
+    "pmi_l2norm_rows": ([_P, _P, _I, _I, _P],),
     "pmi_vit_assemble": ([_P, _P, _P, _P, _I, _I, _I, _I, _P],),
     "pmi_spherical_loss": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P],),
 }

@@ -17,10 +17,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, u16* __restrict__ y16,
                                                             float* __restrict__ y32, float* __restrict__ mean_o,
-                                                            float* __restrict__ rstd_o, int M, int D, float eps) {
+                                                            float* __restrict__ rstd_o, int M, int D, float eps, int ld_x) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
-  const float* xr = x + (int64_t)row * D;
+  const float* xr = x + (int64_t)row * ld_x;
   float s = 0.f;
   for (int c = lane * 4; c < D; c += 256) { const float4 v = *(const float4*)(xr + c); s += v.x + v.y + v.z + v.w; }
   const float mean = wave_sum(s) / D;
@@ -144,6 +144,27 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const u16* __restrict__ dh
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const u16* __restrict__ in, u16* __restrict__ out, int64_t n8, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    float a[8];
+    unpack8<T>(*(const uint4*)(in + i * 8), a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = act_apply(a[e], act);
+    *(uint4*)(out + i * 8) = pack8<T>(a);
+  }
+}
+
+// F.normalize(x, dim=1): y = x / max(|x|, 1e-12), one wave per row
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int M, int D) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float s = 0.f;
+  for (int c = lane; c < D; c += 64) { const float v = x[(int64_t)row * D + c]; s += v * v; }
+  const float inv = 1.f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+  for (int c = lane; c < D; c += 64) y[(int64_t)row * D + c] = x[(int64_t)row * D + c] * inv;
+}
+
 // ---- banded 1-D linear operator along the middle axis of [outer][in_sz][inner] ------------------
 __global__ __launch_bounds__(256) void resize_apply_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                            const int* __restrict__ idx, const float* __restrict__ w,
@@ -255,12 +276,12 @@ __global__ __launch_bounds__(256) void spherical_loss_kernel(const float* __rest
     else hipLaunchKernelGGL(KERN<F16>, grid, block, 0, ST, __VA_ARGS__);                       \
   } while (0)
 
-extern "C" int pmi_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y16, float* y32, float* mean_rstd,
+extern "C" int pmi_layernorm_fwd(const float* x, int ld_x, const float* gamma, const float* beta, void* y16, float* y32, float* mean_rstd,
                                  int M, int D, float eps, int dtype, pmi_stream_t s) {
-  if (!x || !gamma || !beta || (!y16 && !y32) || M <= 0 || D <= 0 || (D & 3)) return PMI_ERR_ARG;
+  if (!x || !gamma || !beta || (!y16 && !y32) || M <= 0 || D <= 0 || (D & 3) || ld_x < D || (ld_x & 3)) return PMI_ERR_ARG;
   dim3 grid((M + 3) / 4), block(256);
   float* mo = mean_rstd; float* ro = mean_rstd ? mean_rstd + M : nullptr;
-  BY_DTYPE(layernorm_fwd_kernel, x, gamma, beta, (u16*)y16, y32, mo, ro, M, D, eps);
+  BY_DTYPE(layernorm_fwd_kernel, x, gamma, beta, (u16*)y16, y32, mo, ro, M, D, eps, ld_x);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }
@@ -320,10 +341,9 @@ extern "C" int pmi_patchify(const float* img, const float* mean, const float* st
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }
-extern "C" int pmi_unpatchify(const float* dcol, const float* stdv, float* dimg, int N, int R, int P, int Kp, int r0, int r1, pmi_stream_t s) {
-  (void)r0; (void)r1;
+extern "C" int pmi_unpatchify(const float* dcol, const float* stdv, float* dimg, int N, int R, int P, int Kp, float mul, pmi_stream_t s) {
   if (!dcol || !stdv || !dimg || N <= 0 || R % P) return PMI_ERR_ARG;
-  hipLaunchKernelGGL(unpatchify_kernel, dim3(grid_for((int64_t)N * 3 * R * R)), dim3(256), 0, ST, dcol, stdv, dimg, N, R, P, Kp, 1.0f);
+  hipLaunchKernelGGL(unpatchify_kernel, dim3(grid_for((int64_t)N * 3 * R * R)), dim3(256), 0, ST, dcol, stdv, dimg, N, R, P, Kp, mul);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }
@@ -340,6 +360,19 @@ extern "C" int pmi_spherical_loss(const float* emb, const float* tgt, const floa
   if (hipMemsetAsync(loss, 0, sizeof(float), ST) != hipSuccess) return PMI_ERR_LAUNCH;
   hipLaunchKernelGGL(spherical_loss_kernel, dim3(N), dim3(256), 0, ST, emb, tgt, wts, loss, demb, N, K, D, mult, gscale,
                      1.0f / ((float)n_total * (float)K));
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_act_fwd(const void* in, void* out, int64_t n, int act, int dtype, pmi_stream_t s) {
+  if (!in || !out || n <= 0 || (n & 7)) return PMI_ERR_ARG;
+  dim3 grid(grid_for(n / 8)), block(256);
+  BY_DTYPE(act_fwd_kernel, (const u16*)in, (u16*)out, n / 8, act);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_l2norm_rows(const float* x, float* y, int M, int D, pmi_stream_t s) {
+  if (!x || !y || M <= 0 || D <= 0) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, x, y, M, D);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }

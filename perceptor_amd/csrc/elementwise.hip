@@ -158,6 +158,30 @@ __global__ __launch_bounds__(256) void guided_kernel(const float* __restrict__ p
   }
 }
 
+// out = ca[n]*a + cb[n]*b + cc[n]  (b / cb optional): every remaining Predictions formula is of this form
+__global__ __launch_bounds__(256) void lincomb2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* ca, const float* cb, const float* cc,
+                                                       float* __restrict__ out, int N, int64_t chw) {
+  const int64_t total = (int64_t)N * chw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int n = (int)(i / chw);
+    float v = ca[n] * a[i];
+    if (b) v += cb[n] * b[i];
+    if (cc) v += cc[n];
+    out[i] = v;
+  }
+}
+
+// clamp with per-sample bounds (static / dynamic thresholding forward)
+__global__ __launch_bounds__(256) void clamp_kernel(const float* __restrict__ a, const float* lo, const float* hi,
+                                                    float* __restrict__ out, int N, int64_t chw) {
+  const int64_t total = (int64_t)N * chw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int n = (int)(i / chw);
+    out[i] = fminf(fmaxf(a[i], lo[n]), hi[n]);
+  }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)s)
@@ -232,6 +256,19 @@ extern "C" int pmi_guided_update(const float* pred, const float* grad, const flo
                                  float* out, int N, int64_t chw, pmi_stream_t s) {
   if (!pred || !grad || !s_from || !out || N <= 0 || chw <= 0 || !(clamp_value > 0.f)) return PMI_ERR_ARG;
   hipLaunchKernelGGL(guided_kernel, dim3(grid_for(N * chw)), dim3(256), 0, ST, pred, grad, s_from, scale, clamp_value, out, N, chw);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_lincomb2(const float* a, const float* b, const float* ca, const float* cb, const float* cc, float* out, int N,
+                            int64_t chw, pmi_stream_t s) {
+  if (!a || !ca || !out || N <= 0 || chw <= 0 || (b && !cb)) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(lincomb2_kernel, dim3(grid_for(N * chw)), dim3(256), 0, ST, a, b, ca, cb, cc, out, N, chw);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_clamp(const float* a, const float* lo, const float* hi, float* out, int N, int64_t chw, pmi_stream_t s) {
+  if (!a || !lo || !hi || !out || N <= 0 || chw <= 0) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(clamp_kernel, dim3(grid_for(N * chw)), dim3(256), 0, ST, a, lo, hi, out, N, chw);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }

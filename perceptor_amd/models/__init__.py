@@ -1,0 +1,3 @@
+"""Drop-in for ``perceptor.models`` on the guided-diffusion hot path."""
+from .guided_diffusion import GuidedDiffusion
+from .open_clip import CLIP, OpenCLIP

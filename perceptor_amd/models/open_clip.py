@@ -1,0 +1,151 @@
+"""OpenCLIP / CLIP image encoders — drop-in for perceptor.models.OpenCLIP and perceptor.models.CLIP.
+
+Call surface of perceptor/models/open_clip.py:12-140 and perceptor/models/clip.py:6-27.  The ViT image
+tower runs in perceptor_amd.engine.vit.VitEngine (HIP); pre-processing is the reference's:
+resize (ResizeRight lanczos3/bicubic) -> Normalize(mean, std) -> tower -> F.normalize.
+
+Not available here (stated loudly instead of faked): pretrained weights (no network;
+``weights="synthetic"`` gives name-keyed deterministic weights, or pass ``checkpoint=`` with an
+open_clip ``visual.*`` state dict), the text tower / tokenizer (``encode_texts``) and ResNet towers.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .. import _hip
+from .._hip import call, ptr
+from ..engine import vit
+from ..utils.synth import synth_state_dict
+
+# (architecture, weights) pairs the reference accepts (docstring of models/open_clip.py:24-44)
+PRETRAINED = {
+    ("ViT-H-14", "laion2b_s32b_b79k"), ("ViT-g-14", "laion2b_s12b_b42k"), ("ViT-L-14", "laion2b_s32b_b82k"),
+    ("ViT-B-32", "laion2b_s34b_b79k"), ("ViT-B-16-plus-240", "laion400m_e32"), ("ViT-B-32", "laion2b_e16"),
+    ("ViT-B-16", "laion400m_e32"), ("ViT-B-32", "laion400m_e32"), ("ViT-L-14", "laion400m_e32"),
+    ("RN101", "yfcc15m"), ("RN50", "yfcc15m"), ("RN50", "cc12m"), ("RN50-quickgelu", "openai"),
+    ("RN101-quickgelu", "openai"), ("RN50x4", "openai"), ("RN50x16", "openai"), ("RN50x64", "openai"),
+    ("ViT-B-32-quickgelu", "openai"), ("ViT-B-16", "openai"), ("ViT-L-14", "openai"), ("ViT-L-14-336", "openai"),
+}
+
+
+class _EncodeImages(torch.autograd.Function):
+    """Lets ``loss(images).backward()`` work as in the reference: forward/backward are the HIP engine's."""
+
+    @staticmethod
+    def forward(ctx, images, model, normalize):
+        emb = model.engine.forward(images, save=True)
+        ctx.model, ctx.normalize = model, normalize
+        ctx.saved_state = model.engine.saved
+        ctx.save_for_backward(emb)
+        if normalize:
+            out = torch.empty_like(emb)
+            call("pmi_l2norm_rows", ptr(emb.contiguous()), ptr(out), emb.shape[0], emb.shape[1])
+            return out
+        return emb.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (emb,) = ctx.saved_tensors
+        eng = ctx.model.engine
+        g = grad_out.float()
+        if ctx.normalize:   # d/d emb of emb/|emb|  (tiny [N, D] tensors)
+            nrm = emb.norm(dim=1, keepdim=True).clamp(min=1e-12)
+            e = emb / nrm
+            g = (g - e * (e * g).sum(dim=1, keepdim=True)) / nrm
+        eng.saved = ctx.saved_state
+        return eng.backward(g * eng.gscale), None, None
+
+
+class OpenCLIP(torch.nn.Module):
+    def __init__(self, architecture="ViT-H-14", weights="laion2b_s32b_b79k", precision=None, *, checkpoint: Optional[str] = None,
+                 seed: int = 0, quick_gelu: Optional[bool] = None, config: Optional[tuple] = None):
+        """
+        Args:
+            architecture (str): name of the clip model
+            weights (str): name of the weights ("synthetic" for deterministic offline weights)
+            precision (str): "bf16" (default on HIP) or "fp16"
+        """
+        super().__init__()
+        self.architecture, self.weights = architecture, weights
+        if weights != "synthetic" and (architecture, weights) not in PRETRAINED:
+            raise ValueError(f"Invalid architecture/weights: {architecture}/{weights}")
+        base = architecture.replace("-quickgelu", "")
+        if config is not None:
+            vit.VIT_CONFIGS.setdefault(base, tuple(config))
+        if base not in vit.VIT_CONFIGS:
+            if weights == "synthetic":
+                raise ValueError(f"Invalid architecture/weights: {architecture}/{weights}")
+            raise NotImplementedError(f"{architecture}: only the ViT image towers {sorted(vit.VIT_CONFIGS)} run on the HIP path")
+        self.cfg = vit.VIT_CONFIGS[base]
+        if weights != "synthetic" and checkpoint is None:
+            raise RuntimeError(f"pretrained weights {architecture}/{weights} cannot be downloaded (no network): "
+                               "pass checkpoint=<visual state dict> or weights='synthetic'")
+        self.quick_gelu = quick_gelu if quick_gelu is not None else ("-quickgelu" in architecture or weights == "openai")
+        self.precision = {None: "bf16", "fp16": "f16", "f16": "f16", "bf16": "bf16", "fp32": "bf16"}[precision]
+        shapes = vit.vit_state_dict_shapes(self.cfg)
+        if checkpoint is not None:
+            sd = torch.load(checkpoint, map_location="cpu", weights_only=True)
+            sd = {k[len("visual."):] if k.startswith("visual.") else k: v.float() for k, v in sd.items()}
+            sd = {k: v for k, v in sd.items() if k in shapes}
+            if set(sd) != set(shapes):
+                raise RuntimeError("checkpoint does not contain the visual tower's tensors")
+        else:
+            sd = synth_state_dict(shapes, seed)
+        self._sd = sd
+        self.anchor = torch.nn.Parameter(torch.zeros(1), requires_grad=False)
+        self.engine: Optional[vit.VitEngine] = None
+        self.output_dim = self.cfg[5]
+
+    def to(self, device):
+        device = torch.device(device)
+        super().to(device)
+        self.engine = vit.VitEngine(self.cfg, self._sd, device, self.precision, self.quick_gelu) if device.type == "cuda" else None
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", device if device is not None else torch.cuda.current_device()))
+
+    @property
+    def device(self):
+        return self.anchor.device
+
+    @property
+    def image_size(self):
+        return (self.cfg[0], self.cfg[0])
+
+    def _need_engine(self):
+        if self.engine is None:
+            raise RuntimeError("OpenCLIP needs a HIP device: call .to('cuda') first (perceptor_amd has no CPU fallback)")
+        return self.engine
+
+    def encode_texts(self, text_prompts, normalize=True):
+        raise NotImplementedError("the CLIP text tower/tokenizer is not part of the HIP hot path yet (SURVEY.md §8f-4); "
+                                  "pass precomputed text embeddings to add_encodings_")
+
+    def encode_images(self, images, normalize=True):
+        self._need_engine()
+        images = images.to(self.device)
+        if images.requires_grad and torch.is_grad_enabled():
+            return _EncodeImages.apply(images, self, normalize)
+        emb = self.engine.forward(images)
+        if normalize:
+            out = torch.empty_like(emb)
+            call("pmi_l2norm_rows", ptr(emb.contiguous()), ptr(out), emb.shape[0], emb.shape[1])
+            return out
+        return emb
+
+    @staticmethod
+    def spherical_distance(encodings_a, encodings_b):
+        return (encodings_a[:, None] - encodings_b[None, :]).norm(dim=2).div(2).arcsin().square().mul(2)
+
+    def forward(self, _):
+        raise NotImplementedError
+
+
+def CLIP(architecture: str, precision: Optional[str] = None, **kw):
+    """perceptor/models/clip.py:6-27 — OpenAI weights; RN50/RN101/ViT-B-32 get the -quickgelu config."""
+    if "-quickgelu" not in architecture and architecture in ["RN50", "RN101", "ViT-B-32"]:
+        architecture = architecture + "-quickgelu"
+    return OpenCLIP(architecture, kw.pop("weights", "openai"), precision, **kw)

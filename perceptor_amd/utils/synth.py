@@ -57,8 +57,13 @@ def synth_tensor(name: str, shape: Sequence[int], seed: int = 0) -> torch.Tensor
     return torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32))
 
 
-def synth_state_dict(shapes: Mapping[str, Sequence[int]], seed: int = 0) -> Dict[str, torch.Tensor]:
-    return {k: synth_tensor(k, v, seed) for k, v in shapes.items()}
+def synth_state_dict(shapes: Mapping[str, Sequence[int]], seed: int = 0, workers: int = 8) -> Dict[str, torch.Tensor]:
+    """Each tensor has its own name-keyed stream, so generation order / threading cannot change values."""
+    from concurrent.futures import ThreadPoolExecutor
+    keys = list(shapes)
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        vals = list(ex.map(lambda k: synth_tensor(k, shapes[k], seed), keys))
+    return dict(zip(keys, vals))
 
 
 def synth_like(state_dict: Mapping[str, torch.Tensor], seed: int = 0) -> Dict[str, torch.Tensor]:

@@ -1,0 +1,94 @@
+"""GPU parity of the CLIP guidance path: resize, ViT embedding, image gradient, spherical loss.
+
+Golden vectors come from the reference's own code (ResizeRight + the in-tree OpenAI-CLIP ViT,
+oracle/gen_golden.py); the oracle (oracle/clip_vit.py) is the fp32 CPU restatement.
+Tolerances: resize is fp32 end to end (1e-5).  The tower runs bf16 GEMM operands with an fp32 residual
+stream: embedding rel-L2 <= 1e-2 (measured 3-5e-3), image-gradient rel-L2 <= 2e-2 (measured 6-7e-3) and cosine >= 0.9995 (the sampler only
+uses the gradient's direction/sign: predictions.py:147-154 clamps it to +-1e-6).
+"""
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+TINY = {"tiny": (32, 8, 64, 2, 1, 32), "tiny-odd": (28, 14, 128, 2, 2, 48)}
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+def _cos(a, b):
+    return float(torch.nn.functional.cosine_similarity(a.double().flatten(), b.double().flatten(), dim=0))
+
+
+def test_resize_forward_matches_reference_and_adjoint():
+    from perceptor_amd.transforms import resize, resize_backward
+    from perceptor_amd.utils.synth import seeded_noise
+    g = golden("clip_resize")
+    for tag, shape, target in (("512_224", (1, 3, 512, 512), (224, 224)), ("256_224", (1, 3, 256, 256), (224, 224)),
+                               ("128_224", (1, 3, 128, 128), (224, 224)), ("96x160_64", (1, 3, 96, 160), (64, 64))):
+        img = (seeded_noise(shape, 51) * 0.25 + 0.5).cuda()
+        out = resize(img, target)
+        assert float((out[:, :, ::3, ::3].cpu() - g["rz_" + tag]).abs().max()) < 5e-6, tag
+        y = seeded_noise(tuple(out.shape), 5).cuda()
+        lhs = float((out.double() * y.double()).sum())
+        rhs = float((img.double() * resize_backward(y, shape[2:]).double()).sum())
+        assert abs(lhs - rhs) <= 1e-4 * abs(lhs) + 1e-4, (tag, lhs, rhs)
+
+
+def _model(tag):
+    from perceptor_amd import models
+    if tag in TINY:
+        return models.OpenCLIP(tag, "synthetic", quick_gelu=True, config=TINY[tag]).to("cuda")
+    return models.OpenCLIP(tag, "synthetic", quick_gelu=True).to("cuda")
+
+
+@pytest.mark.parametrize("tag", ["tiny", "tiny-odd", "ViT-B-32"])
+def test_vit_embedding_and_gradient_vs_reference_golden(tag):
+    g = golden(f"clip_vit_{tag}")
+    model = _model(tag)
+    img = g["img"].cuda().requires_grad_(True)
+    emb = model.encode_images(img, normalize=False)
+    e_rel = _rel(emb.detach().cpu(), g["emb"])
+    with torch.enable_grad():
+        en = model.encode_images(img, normalize=True)
+        (en * g["probe"].cuda()).sum().backward()
+    en_rel = _rel(en.detach().cpu(), g["emb_n"])
+    gr = img.grad.cpu()
+    g_rel = _rel(gr[:, :, ::4, ::4], g["grad_sub"])
+    g_cos = _cos(gr[:, :, ::4, ::4], g["grad_sub"])
+    print(f"[parity] clip {tag}: emb rel-L2={e_rel:.3e}, normalised emb rel-L2={en_rel:.3e}, grad rel-L2={g_rel:.3e}, grad cos={g_cos:.5f}")
+    assert e_rel <= 1e-2 and en_rel <= 1e-2
+    assert g_rel <= 2e-2 and g_cos >= 0.9995
+    f = gr.flatten(1).double()
+    assert torch.allclose(f.norm(dim=1).float(), g["grad_mom"][:, 2], rtol=5e-2)
+
+
+@pytest.mark.parametrize("tag,gelu", [("tiny", False), ("tiny-odd", True)])
+def test_loss_and_grad_vs_oracle_and_sharding(tag, gelu):
+    from oracle import clip_vit
+    from perceptor_amd import losses
+    from perceptor_amd.utils.synth import seeded_noise, synth_state_dict
+    cfg = TINY[tag]
+    loss = losses.OpenCLIP(tag, "synthetic", quick_gelu=gelu, config=cfg).to("cuda")
+    tg = torch.nn.functional.normalize(seeded_noise((3, cfg[5]), 7))
+    w = torch.tensor([1.0, 0.5, 2.0])
+    loss.add_encodings_(tg, w)
+    img = seeded_noise((4, 3, 40, 56), 9) * 0.25 + 0.5
+    l_hip, g_hip = loss.loss_and_grad(img.cuda())
+    sd = synth_state_dict(clip_vit.vit_state_dict_shapes(cfg), 0)
+    l_ref, g_ref = clip_vit.clip_loss_and_grad(sd, cfg, img, tg, w, gelu)
+    print(f"[parity] clip loss {tag}: loss {float(l_hip):.6f} vs {float(l_ref):.6f}, grad rel-L2={_rel(g_hip.cpu(), g_ref):.3e}, cos={_cos(g_hip.cpu(), g_ref):.5f}")
+    assert abs(float(l_hip) - float(l_ref)) <= 5e-3 * abs(float(l_ref))
+    assert _rel(g_hip.cpu(), g_ref) <= 2e-2 and _cos(g_hip.cpu(), g_ref) >= 0.9995
+    # a rank holding half the batch with n_total = 4 reproduces its slice of the full-batch gradient
+    _, g_half = loss.loss_and_grad(img[2:].cuda(), n_total=4)
+    assert float((g_half - g_hip[2:]).abs().max()) <= 1e-6 * float(g_hip.abs().max()) + 1e-12
+    # reference-style call: scalar loss with autograd through the HIP engine
+    x = img.cuda().requires_grad_(True)
+    with torch.enable_grad():
+        loss(x).backward()
+    assert _rel(x.grad.cpu(), g_ref) <= 2e-2
