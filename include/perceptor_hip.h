@@ -72,7 +72,8 @@ int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream);
 int pmi_gn_stats(const void* x, const void* x1, int C0, float* ws, int N, int HW, int C, int G, int nchunk, int dtype, pmi_stream_t s);
 int pmi_gn_finalize(const float* ws, const float* gamma, const float* beta, const float* film, int film_ld,
                     float* coef_a, float* coef_b, int N, int HW, int C, int G, int nchunk, float eps, pmi_stream_t s);
-int pmi_gn_apply(const void* x, const void* x1, int C0, const float* coef_a, const float* coef_b, void* y, int N, int H, int W, int C,
+/* res: optional 16-bit NHWC tensor added after the activation (cc12m_1.py:46-61: relu(mod(norm(conv))) + skip) */
+int pmi_gn_apply(const void* x, const void* x1, int C0, const float* coef_a, const float* coef_b, const void* res, void* y, int N, int H, int W, int C,
                  int act, int pool, int dtype, pmi_stream_t s);
 
 /* ---- attention, head dim 64 (flash-style, MFMA) -----------------------------------
@@ -143,7 +144,7 @@ int pmi_resize_apply(const float* in, float* out, const int* idx, const float* w
 int pmi_patchify(const float* img, const float* mean, const float* stdv, void* col, int N, int R, int P, int Kp, int r0, int dtype, pmi_stream_t s);
 int pmi_unpatchify(const float* dcol, const float* stdv, float* dimg, int N, int R, int P, int Kp, float mul, pmi_stream_t s);
 int pmi_act_fwd(const void* in, void* out, int64_t n, int act, int dtype, pmi_stream_t s);   /* QuickGELU / GELU (ruclip/model.py:20-23) */
-int pmi_l2norm_rows(const float* x, float* y, int M, int D, pmi_stream_t s);                 /* F.normalize, models/open_clip.py:120-121 */
+int pmi_l2norm_rows(const float* x, float* y, int M, int D, float scale, pmi_stream_t s);    /* scale * F.normalize(x): models/open_clip.py:120-121, cc12m_1.py:294 */
 int pmi_vit_assemble(const float* emb, const float* cls, const float* pos, float* x, int N, int T, int D, int r0, pmi_stream_t s);
 /* losses/clip/clip.py:89-99 (+ F.normalize of models/open_clip.py:120-121): loss = mult * sum_{n,k} w_k 2 asin(|e_n-t_k|/2)^2 / (n_total*K);
  * demb = gscale * dloss/demb (emb un-normalised).  n_total = global batch (>= N) so a sharded batch keeps the global mean. */

@@ -51,7 +51,7 @@ _PROTOS = {
     "pmi_igemm": ([C.POINTER(IgemmArgs), _P],),
     "pmi_gn_stats": ([_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],),
     "pmi_gn_finalize": ([_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P],),
-    "pmi_gn_apply": ([_P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],),
+    "pmi_gn_apply": ([_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],),
     "pmi_qkv_split": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],),
     "pmi_attn_d64": ([_P, _P, _P, _P, _I, _I, _I, _F, _I, _P],),
     "pmi_prep_input": ([_P, _P, _I, _P, _I, _I, _I, _I, _I, _P],),
@@ -77,7 +77,7 @@ _PROTOS = {
     "pmi_patchify": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],),
     "pmi_unpatchify": ([_P, _P, _P, _I, _I, _I, _I, _F, _P],),
     "pmi_act_fwd": ([_P, _P, _L, _I, _I, _P],),
-    "pmi_l2norm_rows": ([_P, _P, _I, _I, _P],),
+    "pmi_l2norm_rows": ([_P, _P, _I, _I, _F, _P],),
     "pmi_vit_assemble": ([_P, _P, _P, _P, _I, _I, _I, _I, _P],),
     "pmi_spherical_loss": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P],),
 }

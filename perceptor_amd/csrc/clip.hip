@@ -156,12 +156,12 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const u16* __restrict__ in
 }
 
 // F.normalize(x, dim=1): y = x / max(|x|, 1e-12), one wave per row
-__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int M, int D) {
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int M, int D, float scale) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   float s = 0.f;
   for (int c = lane; c < D; c += 64) { const float v = x[(int64_t)row * D + c]; s += v * v; }
-  const float inv = 1.f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+  const float inv = scale / fmaxf(sqrtf(wave_sum(s)), 1e-12f);
   for (int c = lane; c < D; c += 64) y[(int64_t)row * D + c] = x[(int64_t)row * D + c] * inv;
 }
 
@@ -370,9 +370,9 @@ extern "C" int pmi_act_fwd(const void* in, void* out, int64_t n, int act, int dt
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }
-extern "C" int pmi_l2norm_rows(const float* x, float* y, int M, int D, pmi_stream_t s) {
+extern "C" int pmi_l2norm_rows(const float* x, float* y, int M, int D, float scale, pmi_stream_t s) {
   if (!x || !y || M <= 0 || D <= 0) return PMI_ERR_ARG;
-  hipLaunchKernelGGL(l2norm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, x, y, M, D);
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, ST, x, y, M, D, scale);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }

@@ -95,7 +95,8 @@ __device__ __forceinline__ void affine_act8(const u16* p, const float* a, const 
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const u16* __restrict__ x, const u16* __restrict__ x1, int C0,
                                                        const float* __restrict__ ca, const float* __restrict__ cb,
-                                                       u16* __restrict__ y, int N, int H, int W, int C, int act) {
+                                                       const u16* __restrict__ res, u16* __restrict__ y, int N, int H, int W,
+                                                       int C, int act) {
   const int C8 = C >> 3;
   const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
   const int64_t total = (int64_t)N * Ho * Wo * C8;
@@ -123,6 +124,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const u16* __restrict__ x
       affine_act8<T>(base + (int64_t)W * ld + ld, a, b, act, o, 0.25f);
     } else {
       affine_act8<T>(src + pix * ld, a, b, act, o, 1.f);
+    }
+    if (res) {
+      float r[8];
+      unpack8<T>(*(const uint4*)(res + pix * C + c8 * 8), r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += r[e];
     }
     *(uint4*)(y + pix * C + c8 * 8) = pack8<T>(o);
   }
@@ -156,8 +163,8 @@ extern "C" int pmi_gn_finalize(const float* ws, const float* gamma, const float*
   return PMI_OK;
 }
 
-extern "C" int pmi_gn_apply(const void* x, const void* x1, int C0, const float* coef_a, const float* coef_b, void* y, int N, int H,
-                            int W, int C, int act, int pool, int dtype, pmi_stream_t s) {
+extern "C" int pmi_gn_apply(const void* x, const void* x1, int C0, const float* coef_a, const float* coef_b, const void* res, void* y,
+                            int N, int H, int W, int C, int act, int pool, int dtype, pmi_stream_t s) {
   if (!x1) C0 = C;
   if ((C0 & 7) || C0 <= 0 || C0 > C) return PMI_ERR_ARG;
   if (!x || !y || !coef_a || !coef_b || N <= 0 || H <= 0 || W <= 0 || (C & 7)) return PMI_ERR_ARG;
@@ -165,7 +172,7 @@ extern "C" int pmi_gn_apply(const void* x, const void* x1, int C0, const float* 
   const int64_t work = (int64_t)N * (pool ? H / 2 : H) * (pool ? W / 2 : W) * (C / 8);
   dim3 grid(grid_for(work)), block(256);
   hipStream_t st = (hipStream_t)s;
-#define GO(TT, PP) hipLaunchKernelGGL((gn_apply_kernel<TT, PP>), grid, block, 0, st, (const u16*)x, (const u16*)x1, C0, coef_a, coef_b, (u16*)y, N, H, W, C, act)
+#define GO(TT, PP) hipLaunchKernelGGL((gn_apply_kernel<TT, PP>), grid, block, 0, st, (const u16*)x, (const u16*)x1, C0, coef_a, coef_b, (const u16*)res, (u16*)y, N, H, W, C, act)
   if (dtype == PMI_DT_BF16) { if (pool) GO(BF16, true); else GO(BF16, false); }
   else { if (pool) GO(F16, true); else GO(F16, false); }
 #undef GO

@@ -123,7 +123,7 @@ def bgemm(A: torch.Tensor, B: torch.Tensor, D: torch.Tensor, *, M: int, N: int, 
 
 
 def group_norm(x: torch.Tensor, gamma, beta, groups: int, dt: int, *, x1: Optional[torch.Tensor] = None,
-               film: Optional[torch.Tensor] = None, film_ld: int = 0,
+               film: Optional[torch.Tensor] = None, film_ld: int = 0, residual: Optional[torch.Tensor] = None,
                act: int = ACT_NONE, pool: bool = False, eps: float = 1e-5) -> torch.Tensor:
     """GroupNorm over the channel-concat of x (and x1) -> act(norm * gamma + beta [FiLM]) [-> 2x2 avg pool]."""
     n, h, w, c0 = x.shape
@@ -137,7 +137,7 @@ def group_norm(x: torch.Tensor, gamma, beta, groups: int, dt: int, *, x1: Option
     call("pmi_gn_stats", ptr(x), ptr(x1), c0, ptr(ws), n, hw, c, groups, nchunk, dt)
     call("pmi_gn_finalize", ptr(ws), ptr(gamma), ptr(beta), ptr(film), film_ld, ptr(ca), ptr(cb), n, hw, c, groups, nchunk, eps)
     y = _empty((n, h // 2, w // 2, c) if pool else (n, h, w, c), x.dtype, dev)
-    call("pmi_gn_apply", ptr(x), ptr(x1), c0, ptr(ca), ptr(cb), ptr(y), n, h, w, c, act, int(pool), dt)
+    call("pmi_gn_apply", ptr(x), ptr(x1), c0, ptr(ca), ptr(cb), ptr(residual), ptr(y), n, h, w, c, act, int(pool), dt)
     return y
 
 

@@ -1,0 +1,266 @@
+"""HIP engine for the v-diffusion UNets (yfcc_2, cc12m_1 and same-family nets).
+
+Replaces YFCC2Model.forward (perceptor/models/velocity_diffusion/yfcc_2.py:247-249, blocks :17-70)
+and CC12M1Model.forward (cc12m_1.py:293-302, blocks :19-61).  The reference's nested nn.Sequential
+is described by a list program (levels -> [blocks, Skip[...], blocks]); state-dict keys follow from
+list positions exactly as nn.Sequential numbers them.
+
+Kernel mapping: conv3x3 (+bias +ReLU +residual) and the bias-free 1x1 skips are pmi_igemm launches,
+SkipBlock's torch.cat is never materialised (two source pointers in the K loop), AvgPool2d /
+bilinear x2 are streaming kernels, SelfAttention2d = GroupNorm(1,C) -> 1x1 qkv -> flash attention
+(d = 64) -> 1x1 out + residual.  cc12m_1: GroupNorm(1,C,affine=False) + Modulation2d + ReLU is one
+stats/finalize/apply chain whose FiLM coefficients for ALL blocks come from a single GEMM on the
+mapping network's output.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .. import _hip
+from .._hip import ACT_NONE, ACT_RELU, call, ptr
+from . import ops
+from .ops import PackedLinear
+
+
+class Res:
+    def __init__(self, cin, cmid, cout, last=False):
+        self.cin, self.cmid, self.cout, self.last = cin, cmid, cout, last
+        self.mod1 = self.mod2 = 0
+
+
+class Attn:
+    def __init__(self, c):
+        self.c = c
+
+
+class Down:
+    pass
+
+
+class Up:
+    pass
+
+
+class Skip:
+    def __init__(self, main):
+        self.main = main
+
+
+def _level(cs: List[int], i: int, attn_from: int, side: int, inner: int) -> list:
+    """Contents of the SkipBlock running at resolution level i (i = 1 is the first down-sampled level)."""
+    prog: list = [Down()]
+
+    def block(a, b, c):
+        prog.append(Res(a, b, c))
+        if i >= attn_from:
+            prog.append(Attn(c))
+
+    if i < len(cs) - 1:
+        block(cs[i - 1], cs[i], cs[i])
+        for _ in range(side - 1):
+            block(cs[i], cs[i], cs[i])
+        prog.append(Skip(_level(cs, i + 1, attn_from, side, inner)))
+        block(2 * cs[i], cs[i], cs[i])
+        for _ in range(side - 2):
+            block(cs[i], cs[i], cs[i])
+        block(cs[i], cs[i], cs[i - 1])
+    else:
+        block(cs[i - 1], cs[i], cs[i])
+        for _ in range(inner - 2):
+            block(cs[i], cs[i], cs[i])
+        block(cs[i], cs[i], cs[i - 1])
+    prog.append(Up())
+    return prog
+
+
+def make_spec(name: str, shape, cs: List[int], top: int, side: int, inner: int, attn_from: int, cond: bool, feats: int = 1024):
+    prog = [Res(3 + 16, cs[0], cs[0])] + [Res(cs[0], cs[0], cs[0]) for _ in range(top - 1)]
+    prog.append(Skip(_level(cs, 1, attn_from, side, inner)))
+    prog.append(Res(2 * cs[0], cs[0], cs[0]))
+    prog += [Res(cs[0], cs[0], cs[0]) for _ in range(top - 2)]
+    prog.append(Res(cs[0], cs[0], 3, last=True))
+    return dict(name=name, shape=tuple(shape), cond=cond, feats=feats, net=prog)
+
+
+def yfcc2_spec():   # yfcc_2.py:77-245
+    c = 256
+    return make_spec("yfcc_2", (3, 512, 512), [c // 2, c, c * 2, c * 2, c * 4, c * 4, c * 8, c * 8], 2, 2, 4, 5, False)
+
+
+def cc12m1_spec():  # cc12m_1.py:112-291
+    c = 128
+    return make_spec("cc12m_1", (3, 256, 256), [c, c * 2, c * 2, c * 4, c * 4, c * 8, c * 8], 4, 4, 8, 4, True)
+
+
+def _walk(prog, prefix, fn):
+    for i, l in enumerate(prog):
+        p = f"{prefix}.{i}"
+        if isinstance(l, Skip):
+            _walk(l.main, p + ".main", fn)
+        else:
+            fn(l, p)
+
+
+def state_dict_shapes(spec) -> Dict[str, Tuple[int, ...]]:
+    S: Dict[str, Tuple[int, ...]] = {}
+    cond, f = spec["cond"], spec["feats"]
+    if cond:
+        S["mapping_timestep_embed.weight"] = (64, 1)
+        S["mapping.0.main.0.weight"] = (f, 640); S["mapping.0.main.0.bias"] = (f,)
+        S["mapping.0.main.2.weight"] = (f, f); S["mapping.0.main.2.bias"] = (f,)
+        S["mapping.0.skip.weight"] = (f, 640)
+        S["mapping.1.main.0.weight"] = (f, f); S["mapping.1.main.0.bias"] = (f,)
+        S["mapping.1.main.2.weight"] = (f, f); S["mapping.1.main.2.bias"] = (f,)
+    S["timestep_embed.weight"] = (8, 1)
+
+    def add(l, p):
+        if isinstance(l, Res):
+            j = 4 if cond else 2
+            S[p + ".main.0.weight"] = (l.cmid, l.cin, 3, 3); S[p + ".main.0.bias"] = (l.cmid,)
+            S[p + f".main.{j}.weight"] = (l.cout, l.cmid, 3, 3); S[p + f".main.{j}.bias"] = (l.cout,)
+            if cond:
+                S[p + ".main.2.layer.weight"] = (2 * l.cmid, f)
+                if not l.last:
+                    S[p + ".main.6.layer.weight"] = (2 * l.cout, f)
+            if l.cin != l.cout:
+                S[p + ".skip.weight"] = (l.cout, l.cin, 1, 1)
+        elif isinstance(l, Attn):
+            S[p + ".norm.weight"] = (l.c,); S[p + ".norm.bias"] = (l.c,)
+            S[p + ".qkv_proj.weight"] = (3 * l.c, l.c, 1, 1); S[p + ".qkv_proj.bias"] = (3 * l.c,)
+            S[p + ".out_proj.weight"] = (l.c, l.c, 1, 1); S[p + ".out_proj.bias"] = (l.c,)
+
+    _walk(spec["net"], "net", add)
+    return S
+
+
+class VDiffEngine:
+    def __init__(self, spec, state_dict, device, dtype="bf16"):
+        self.spec, self.device = spec, torch.device(device)
+        self.dt = _hip.dtype_code(dtype)
+        _hip.lib()
+        sd, dev, dt = state_dict, self.device, self.dt
+        self.cond = spec["cond"]
+        f32 = lambda k: sd[k].detach().float().to(dev).contiguous()
+        self.w: Dict[str, object] = {}
+        mods, off = [], [0]
+        first = [True]
+
+        def pack(l, p):
+            if isinstance(l, Res):
+                j = 4 if self.cond else 2
+                self.w[p + ".c1"] = PackedLinear(sd[p + ".main.0.weight"], sd[p + ".main.0.bias"], dt, dev,
+                                                 cin_pad=24 if first[0] else None)
+                first[0] = False
+                self.w[p + ".c2"] = PackedLinear(sd[p + f".main.{j}.weight"], sd[p + f".main.{j}.bias"], dt, dev)
+                if l.cin != l.cout:
+                    self.w[p + ".skip"] = PackedLinear(sd[p + ".skip.weight"], None, dt, dev, cin_pad=24 if l.cin == 19 else None)
+                if self.cond:
+                    l.mod1 = off[0]; mods.append(sd[p + ".main.2.layer.weight"].float()); off[0] += 2 * l.cmid
+                    if not l.last:
+                        l.mod2 = off[0]; mods.append(sd[p + ".main.6.layer.weight"].float()); off[0] += 2 * l.cout
+            elif isinstance(l, Attn):
+                self.w[p + ".gn"] = (f32(p + ".norm.weight"), f32(p + ".norm.bias"))
+                self.w[p + ".qkv"] = PackedLinear(sd[p + ".qkv_proj.weight"], sd[p + ".qkv_proj.bias"], dt, dev)
+                self.w[p + ".out"] = PackedLinear(sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"], dt, dev)
+
+        _walk(spec["net"], "net", pack)
+        self.tw = f32("timestep_embed.weight").reshape(-1)
+        if self.cond:
+            self.mod_all = PackedLinear(torch.cat(mods, 0), None, dt, dev)
+            self.mtw = f32("mapping_timestep_embed.weight").reshape(-1)
+            L = lambda k, bias=True: PackedLinear(sd[k + ".weight"], sd.get(k + ".bias") if bias else None, dt, dev)
+            self.m = dict(a0=L("mapping.0.main.0"), a2=L("mapping.0.main.2"), askip=L("mapping.0.skip", False),
+                          b0=L("mapping.1.main.0"), b2=L("mapping.1.main.2"))
+
+    # ---- blocks --------------------------------------------------------------------------------------
+    def _res(self, l: Res, p, x, x1, mod):
+        dt, w = self.dt, self.w
+        skip = x
+        if l.cin != l.cout:
+            skip = ops.igemm(x, w[p + ".skip"], a1=x1)
+        elif x1 is not None:
+            raise NotImplementedError("identity skip over a concatenated input does not occur in this model family")
+        if not self.cond:
+            h = ops.igemm(x, w[p + ".c1"], a1=x1, act=ACT_RELU)
+            if l.last:
+                return ops.igemm(h, w[p + ".c2"], residual=skip, out_f32=True)
+            return ops.igemm(h, w[p + ".c2"], act=ACT_RELU, residual=skip)
+        ld = mod.stride(0)
+        h = ops.igemm(x, w[p + ".c1"], a1=x1)
+        h = ops.group_norm(h, None, None, 1, dt, film=mod[:, l.mod1:], film_ld=ld, act=ACT_RELU)
+        if l.last:
+            return ops.igemm(h, w[p + ".c2"], residual=skip, out_f32=True)
+        h = ops.igemm(h, w[p + ".c2"])
+        return ops.group_norm(h, None, None, 1, dt, film=mod[:, l.mod2:], film_ld=ld, act=ACT_RELU, residual=skip)
+
+    def _attn(self, l: Attn, p, x):
+        dt, w = self.dt, self.w
+        n, hh, ww, c = x.shape
+        g, b = w[p + ".gn"]
+        hn = ops.group_norm(x, g, b, 1, dt)
+        qkv = ops.igemm(hn.view(n * hh * ww, c), w[p + ".qkv"])
+        a = ops.attention(qkv.view(n, hh * ww, 3 * c), c // 64, 1, dt)
+        return ops.igemm(a.view(n * hh * ww, c), w[p + ".out"], residual=x.view(n * hh * ww, c)).view(n, hh, ww, c)
+
+    def _run(self, prog, prefix, x, mod):
+        x1 = None
+        for i, l in enumerate(prog):
+            p = f"{prefix}.{i}"
+            if isinstance(l, Res):
+                x, x1 = self._res(l, p, x, x1, mod), None
+            elif isinstance(l, Attn):
+                x = self._attn(l, p, x)
+            elif isinstance(l, Down):
+                x = ops.avgpool2(x, self.dt)
+            elif isinstance(l, Up):
+                x = ops.upsample_bilinear2(x, self.dt)
+            elif isinstance(l, Skip):
+                # torch.cat([main(x), x], dim=1): main first, then the skip path (yfcc_2.py:31-38)
+                x, x1 = self._run(l.main, p + ".main", x, mod), x
+        assert x1 is None
+        return x
+
+    def _mapping(self, t, clip_embed):
+        dt, dev = self.dt, self.device
+        n = t.shape[0]
+        tdt = _hip.TORCH_DTYPE[dt]
+        ce = clip_embed.to(device=dev, dtype=torch.float32).contiguous()
+        cen = torch.empty_like(ce)
+        call("pmi_l2norm_rows", ptr(ce), ptr(cen), n, ce.shape[1], float(ce.shape[1]) ** 0.5)      # cc12m_1.py:294
+        ff = torch.empty((n, 2 * self.mtw.numel()), dtype=torch.float32, device=dev)
+        call("pmi_fourier_features", ptr(t), ptr(self.mtw), ptr(ff), n, self.mtw.numel())
+        ce16, ff16 = torch.empty(cen.shape, dtype=tdt, device=dev), torch.empty(ff.shape, dtype=tdt, device=dev)
+        call("pmi_cast_f32_to_16", ptr(cen), ptr(ce16), cen.numel(), ACT_NONE, dt)
+        call("pmi_cast_f32_to_16", ptr(ff), ptr(ff16), ff.numel(), ACT_NONE, dt)
+        m = self.m
+        h = ops.igemm(ce16, m["a0"], a1=ff16, act=ACT_RELU)       # Linear on cat([clip_embed, fourier]) without the cat
+        s = ops.igemm(ce16, m["askip"], a1=ff16)
+        z1 = ops.igemm(h, m["a2"], act=ACT_RELU, residual=s)
+        h = ops.igemm(z1, m["b0"], act=ACT_RELU)
+        cond = ops.igemm(h, m["b2"], residual=z1)
+        return ops.igemm(cond, self.mod_all, out_f32=True)           # every Modulation2d's (scale|shift) at once
+
+    @torch.no_grad()
+    def forward(self, images: torch.Tensor, t: torch.Tensor, clip_embed: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """images NCHW fp32 in [0,1]; t [N] float in (0,1]; returns v, NCHW fp32 [N,3,H,W]."""
+        if not images.is_cuda:
+            raise RuntimeError("VDiffEngine runs on a HIP device only (no CPU fallback)")
+        dt, dev = self.dt, self.device
+        images = images.float().contiguous()
+        n, _, hh, ww = images.shape
+        t = t.to(device=dev, dtype=torch.float32).contiguous()
+        mod = None
+        if self.cond:
+            if clip_embed is None:
+                raise ValueError("this model is CLIP-conditioned: clip_embed is required")
+            mod = self._mapping(t, clip_embed)
+        planes = torch.empty((n, 16), dtype=torch.float32, device=dev)
+        call("pmi_fourier_features", ptr(t), ptr(self.tw), ptr(planes), n, 8)
+        x = torch.empty((n, hh, ww, 24), dtype=_hip.TORCH_DTYPE[dt], device=dev)
+        call("pmi_prep_input", ptr(images), ptr(planes), 16, ptr(x), n, hh, ww, 24, dt)
+        y = self._run(self.spec["net"], "net", x, mod)
+        out = torch.empty((n, 3, hh, ww), dtype=torch.float32, device=dev)
+        call("pmi_finish_output", ptr(y), y.shape[-1], ptr(out), n, hh, ww, 3)
+        return out

@@ -1,3 +1,4 @@
 """Drop-in for ``perceptor.models`` on the guided-diffusion hot path."""
 from .guided_diffusion import GuidedDiffusion
 from .open_clip import CLIP, OpenCLIP
+from .velocity_diffusion import VelocityDiffusion
