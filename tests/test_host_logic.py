@@ -1,0 +1,105 @@
+"""CPU: host-side logic of the drop-in classes (schedules, shapes, packing, resize tables, error behaviour)
+against the reference's golden vectors.  No HIP compute."""
+import pytest
+import torch
+
+from conftest import golden
+
+
+def test_schedule_indices_and_tables_match_reference():
+    from perceptor_amd import models
+    g = golden("sampling")
+    m = models.GuidedDiffusion("pixelart")
+    assert torch.equal(m.schedule_alphas.data, g["alphas"]) and torch.equal(m.schedule_sigmas.data, g["sigmas"])
+    assert torch.equal(m.schedule_indices(n_steps=50, rho=3.0), g["idx_50_r3"])
+    assert torch.equal(m.schedule_indices(n_steps=250, rho=7.0), g["idx_250_r7"])
+    assert torch.equal(m.schedule_indices(n_steps=20, from_index=400, to_index=0), g["idx_20_400"])
+    with pytest.raises(ValueError):
+        m.schedule_indices(from_index=0, to_index=10)
+    with pytest.raises(ValueError):
+        m.random_diffused((1, 3, 30, 32))
+    with pytest.raises(ValueError):
+        m.indices(torch.zeros(2, 2))
+    with pytest.raises(RuntimeError):           # no CPU fallback
+        m.predicted_noise(torch.zeros(1, 3, 64, 64), 10)
+    assert m.shape == (3, 256, 256) and m.alphas(5).shape == (1, 1, 1, 1)
+
+
+def test_schedule_ts_matches_reference():
+    from perceptor_amd import models
+    g = golden("sampling")
+    assert torch.allclose(models.VelocityDiffusion.schedule_ts(n_steps=50), g["ts_50"], atol=1e-6)
+    assert torch.allclose(models.VelocityDiffusion.schedule_ts(), g["ts_500"], atol=1e-6)
+    s = torch.tensor([0.1, 0.7])
+    t = models.VelocityDiffusion.sigmas_to_ts(s)
+    assert torch.allclose(torch.sin(t * torch.pi / 2), s, atol=1e-6)   # reference test_convert_sigma_ts
+
+
+def test_state_dict_surface_and_key_compatibility():
+    from oracle import adm_unet, vdiff as ov
+    from perceptor_amd.engine import adm, vdiff
+    assert adm.state_dict_shapes(adm.openimages_config()) == adm_unet.state_dict_shapes(adm_unet.openimages_config())
+    assert adm.state_dict_shapes(adm.pixelart_config()) == adm_unet.state_dict_shapes(adm_unet.pixelart_config())
+    assert vdiff.state_dict_shapes(vdiff.yfcc2_spec()) == ov.state_dict_shapes(ov.yfcc2_spec())
+    assert vdiff.state_dict_shapes(vdiff.cc12m1_spec()) == ov.state_dict_shapes(ov.cc12m1_spec())
+    from perceptor_amd import models
+    m = models.GuidedDiffusion("pixelart")
+    sd = m.model.state_dict()
+    assert len(sd) == 426 and "input_blocks.0.0.weight" in sd and sd["out.2.weight"].shape == (6, 128, 3, 3)
+    m.model.load_state_dict(sd)
+    with pytest.raises(RuntimeError):
+        m.model.load_state_dict({"bogus": torch.zeros(1)})
+
+
+def test_weight_packing_layout():
+    from perceptor_amd.engine.ops import PackedLinear
+    w = torch.arange(2 * 3 * 3 * 3, dtype=torch.float32).reshape(2, 3, 3, 3)
+    p = PackedLinear(w, torch.tensor([1.0, 2.0]), 0, "cpu", cin_pad=8)
+    assert p.w.shape == (4, 72) and p.taps == 9 and p.K == 72 and p.n_p == 4
+    # k = tap * Cin_pad + c with tap = ky*3 + kx
+    assert float(p.w[1, (1 * 3 + 2) * 8 + 2]) == float(w[1, 2, 1, 2])
+    assert float(p.w[0, 5]) == 0.0 and p.b.tolist() == [1.0, 2.0, 0.0, 0.0]
+
+
+def test_resize_tables_equal_dense_oracle_operator():
+    from oracle import clip_vit
+    from perceptor_amd.transforms.resize import band_tables
+    for i, o, method in ((512, 224, "lanczos3"), (256, 224, "lanczos3"), (128, 224, "cubic"), (160, 64, "lanczos3")):
+        idx, w, idx_t, w_t = band_tables(i, o, method)
+        dense = torch.zeros(o, i)
+        for j in range(o):
+            for k in range(idx.shape[1]):
+                if idx[j, k] >= 0:
+                    dense[j, idx[j, k]] += w[j, k]
+        assert torch.allclose(dense, clip_vit.resize_matrix(i, o, method), atol=1e-7)
+        dense_t = torch.zeros(i, o)
+        for r in range(i):
+            for k in range(idx_t.shape[1]):
+                if idx_t[r, k] >= 0:
+                    dense_t[r, idx_t[r, k]] += w_t[r, k]
+        assert torch.equal(dense_t, dense.T)
+
+
+def test_wrapper_errors_and_records():
+    from perceptor_amd import losses, models
+    from perceptor_amd.models.guided_diffusion import Predictions
+    with pytest.raises(ValueError):
+        models.OpenCLIP("ViT-B-32", "not-a-tag")
+    with pytest.raises(RuntimeError):
+        models.OpenCLIP("ViT-B-32", "laion2b_s34b_b79k")       # valid pair, but weights are not downloadable here
+    with pytest.raises(KeyError):
+        models.VelocityDiffusion("nope")
+    c = models.CLIP("ViT-B-32", weights="synthetic")
+    assert c.architecture == "ViT-B-32-quickgelu" and c.quick_gelu and c.image_size == (224, 224)
+    l = losses.CLIP("ViT-L-14", weights="synthetic")
+    assert l.multiplier == 0.01 and l.mul_(2.0).multiplier == 0.02
+    with pytest.raises(ValueError):
+        l.add_text_off_()
+    z = torch.zeros(1, 3, 4, 4)
+    p = Predictions(from_diffused_images=z, from_indices=torch.tensor([3]), predicted_noise=z,
+                    schedule_alphas=torch.ones(10), schedule_sigmas=torch.ones(10))
+    with pytest.raises(AttributeError):
+        p.predicted_noise = z
+    assert p.replace(predicted_noise=z + 1).predicted_noise.sum() == 48
+    d = models.OpenCLIP.spherical_distance(torch.eye(3)[:1], torch.eye(3)[1:2])
+    assert torch.allclose(d, torch.tensor([[torch.pi**2 / 8]]))

@@ -115,3 +115,19 @@ def test_spherical_loss_known_values():
     d = (e[:, None] - t[None]).norm(dim=2).div(2).arcsin().square().mul(2)
     assert torch.allclose(d[0], torch.tensor([0.0, torch.pi**2 / 8, torch.pi**2 / 2]), atol=1e-5)
     assert torch.allclose(clip_vit.spherical_loss(e, t, torch.ones(3)), d.mean(), atol=1e-6)
+
+
+def test_vdiff_yfcc2_full_128():
+    g = golden("vdiff_yfcc_2_128")
+    spec = vdiff.yfcc2_spec()
+    sd = synth_state_dict(vdiff.state_dict_shapes(spec), 0)
+    y = vdiff.vdiff_forward(sd, spec, g["x"], g["t"])
+    _close(y[:, :, ::4, ::4], g["y_sub"], 1e-5)
+
+
+def test_vdiff_cc12m1_full_64():
+    g = golden("vdiff_cc12m_1_64")
+    spec = vdiff.cc12m1_spec()
+    sd = synth_state_dict(vdiff.state_dict_shapes(spec), 0)
+    y = vdiff.vdiff_forward(sd, spec, g["x"], g["t"], g["clip_embed"])
+    _close(y[:, :, ::2, ::2], g["y_sub"], 1e-5)
