@@ -41,6 +41,10 @@ typedef struct {
   const float* nbias;  /* [M/hw][N] per-sample bias or NULL */
   const void* R;       /* residual or NULL */
   void* D;
+  const float* pro_a;  /* optional fused input prologue x <- pro_act(x * pro_a[img][c] + pro_b[img][c]) (GroupNorm-apply+FiLM+SiLU */
+  const float* pro_b;  /* of the consumer's input, zero padding stays zero); only where pmi_conv3x3_halo_config() >= 0 */
+  void* ws;            /* split-K workspace: splitk * M * N floats (caller-owned), NULL when splitk <= 1 */
+  float* stats;        /* optional: per-channel (sum, sumsq) partials of the OUTPUT, [img][stats_p][N][2] fp32, for the next GroupNorm */
   int32_t M, N, K;     /* K % 8 == 0; N % 4 == 0 unless bias/nbias/R are NULL and ldd >= roundup(N,4) */
   int32_t C0, C1;      /* channel split of the K index (C0 + C1 = Cin) */
   int32_t lda0, lda1;  /* elements between consecutive pixels/rows of A0 / A1 */
@@ -58,20 +62,36 @@ typedef struct {
   int64_t sA_o, sA_i, sB_o, sB_i, sD_o, sD_i, sR_o, sR_i; /* element strides */
   int32_t dtype;       /* 0 f16, 1 bf16 */
   int32_t ldnb;        /* row pitch of nbias (0 = N) */
+  int32_t pro_act;     /* activation of the fused prologue */
+  int32_t stats_p;     /* partial rows per image = pmi_igemm_stats_rows(); 0 = no statistics */
+  int32_t splitk;      /* <= 1: none; else K is split over grid.z and reduced by a second kernel (see pmi_igemm_splitk) */
+  int32_t reserved;
 } pmi_igemm_args;
 int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream);
+/* >= 0 when the LDS-halo conv3x3 kernel (csrc/conv3x3.hip) takes this shape (tile config 0: 8x32 px x 256 ch, 1: 16x32 x 128, 2: 8x32 x 128),
+ * -1 when pmi_igemm uses the generic implicit-GEMM kernel (which has no fused prologue). */
+int pmi_conv3x3_halo_config(const pmi_igemm_args* a);
+/* split-K factor recommended for this shape (1 = none); with splitk = S the caller passes ws = S*M*N floats */
+int pmi_igemm_splitk(const pmi_igemm_args* a);
+/* number of per-image partial rows the fused output statistics of this call would produce (0: not available for this shape) */
+int pmi_igemm_stats_rows(const pmi_igemm_args* a);
+/* debugging / A-B switches: key 0 = allow the LDS-halo conv3x3 kernel (default 1, returns the previous value);
+ * key 1 = force halo tile config 0/1/2 where eligible (-1 = automatic). */
+int pmi_set_option(int key, int value);
 
 /* ---- GroupNorm (+FiLM, +activation, +2x2 average pool) ---------------------------
  * unet.py:232-252 / nn.py:17-19 (GroupNorm32 -> SiLU, FiLM h*(1+scale)+shift),
  * yfcc_2.py:56 (GroupNorm(1,C)), cc12m_1.py:33-61 (GroupNorm(1,C,affine=False) + Modulation2d + ReLU).
- * stats: partial sums per (sample, pixel-chunk, group) -> ws[N][nchunk][G][2] (fp32)
+ * stats: partial sums per (sample, pixel-chunk, channel) -> ws[N][nchunk][C][2] (fp32)
  * finalize: coefficients a[n][c], b[n][c] so that y = act(x * a + b)
  * apply: y (optionally 2x2 average-pooled after the activation)                      */
 /* x1/C0: optional second source: channels [0,C0) from x, [C0,C) from x1 (normalising a skip-concat, unet.py:650-652,
  * without materialising it); pass x1 = NULL, C0 = C otherwise. */
 int pmi_gn_stats(const void* x, const void* x1, int C0, float* ws, int N, int HW, int C, int G, int nchunk, int dtype, pmi_stream_t s);
-int pmi_gn_finalize(const float* ws, const float* gamma, const float* beta, const float* film, int film_ld,
-                    float* coef_a, float* coef_b, int N, int HW, int C, int G, int nchunk, float eps, pmi_stream_t s);
+/* finalize from per-CHANNEL partials s0[N][P0][C0][2] (and optionally s1[N][P1][C1][2] for the second half of a concat):
+ * the layout pmi_gn_stats and the fused statistics epilogue of pmi_igemm both write. */
+int pmi_gn_finalize(const float* s0, int P0, int C0, const float* s1, int P1, int C1, const float* gamma, const float* beta,
+                    const float* film, int film_ld, float* coef_a, float* coef_b, int N, int HW, int G, float eps, pmi_stream_t s);
 /* res: optional 16-bit NHWC tensor added after the activation (cc12m_1.py:46-61: relu(mod(norm(conv))) + skip) */
 int pmi_gn_apply(const void* x, const void* x1, int C0, const float* coef_a, const float* coef_b, const void* res, void* y, int N, int H, int W, int C,
                  int act, int pool, int dtype, pmi_stream_t s);

@@ -30,7 +30,7 @@ def dtype_code(name) -> int:
 class IgemmArgs(C.Structure):
     _fields_ = [
         ("A0", C.c_void_p), ("A1", C.c_void_p), ("B", C.c_void_p), ("bias", C.c_void_p), ("nbias", C.c_void_p),
-        ("R", C.c_void_p), ("D", C.c_void_p),
+        ("R", C.c_void_p), ("D", C.c_void_p), ("pro_a", C.c_void_p), ("pro_b", C.c_void_p), ("ws", C.c_void_p), ("stats", C.c_void_p),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("C0", C.c_int32), ("C1", C.c_int32),
         ("lda0", C.c_int32), ("lda1", C.c_int32), ("ldb", C.c_int32), ("ldd", C.c_int32), ("ldr", C.c_int32),
         ("H", C.c_int32), ("W", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32),
@@ -39,7 +39,7 @@ class IgemmArgs(C.Structure):
         ("batch", C.c_int32), ("batch_inner", C.c_int32),
         ("sA_o", C.c_int64), ("sA_i", C.c_int64), ("sB_o", C.c_int64), ("sB_i", C.c_int64),
         ("sD_o", C.c_int64), ("sD_i", C.c_int64), ("sR_o", C.c_int64), ("sR_i", C.c_int64),
-        ("dtype", C.c_int32), ("ldnb", C.c_int32),
+        ("dtype", C.c_int32), ("ldnb", C.c_int32), ("pro_act", C.c_int32), ("stats_p", C.c_int32), ("splitk", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -49,8 +49,12 @@ _I, _F, _P, _L = C.c_int, C.c_float, C.c_void_p, C.c_int64
 _PROTOS = {
     "pmi_abi_version": ([], ),
     "pmi_igemm": ([C.POINTER(IgemmArgs), _P],),
+    "pmi_conv3x3_halo_config": ([C.POINTER(IgemmArgs)],),
+    "pmi_igemm_stats_rows": ([C.POINTER(IgemmArgs)],),
+    "pmi_igemm_splitk": ([C.POINTER(IgemmArgs)],),
+    "pmi_set_option": ([_I, _I],),
     "pmi_gn_stats": ([_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],),
-    "pmi_gn_finalize": ([_P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P],),
+    "pmi_gn_finalize": ([_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _F, _P],),
     "pmi_gn_apply": ([_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],),
     "pmi_qkv_split": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],),
     "pmi_attn_d64": ([_P, _P, _P, _P, _I, _I, _I, _F, _I, _P],),

@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libperceptor_hip.so")
-SOURCES = ["igemm.hip", "norm.hip", "attn.hip", "elementwise.hip", "clip.hip"]
+SOURCES = ["igemm.hip", "conv3x3.hip", "norm.hip", "attn.hip", "elementwise.hip", "clip.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 
 

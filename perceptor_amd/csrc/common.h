@@ -66,9 +66,9 @@ __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
 __device__ __forceinline__ float act_apply(float x, int act) {
   switch (act) {
     case PMI_ACT_RELU: return x > 0.f ? x : 0.f;
-    case PMI_ACT_SILU: return x / (1.f + __expf(-x));
+    case PMI_ACT_SILU: return x * __builtin_amdgcn_rcpf(1.f + __expf(-x));       // v_rcp_f32 (1 ulp), no IEEE division sequence
     case PMI_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
-    case PMI_ACT_QUICKGELU: return x / (1.f + __expf(-1.702f * x));
+    case PMI_ACT_QUICKGELU: return x * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * x));
     default: return x;
   }
 }

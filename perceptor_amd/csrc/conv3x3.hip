@@ -1,0 +1,308 @@
+// conv3x3 (stride 1, pad 1) as an LDS-halo implicit GEMM for gfx950 MFMA — the dominant kernel of the UNets.
+//
+// A 512-thread workgroup (8 waves) owns a TH x 32 pixel tile x BN output channels.  Per 64-channel input chunk
+// the (TH+2) x 34 halo patch is staged into LDS ONCE and serves all 9 taps (the generic kernel re-gathers it
+// per tap: 9x the L2->LDS traffic and 9x the address arithmetic); per tap only the [BN][64] weight tile moves
+// (double-buffered, register-prefetched one tap ahead).  Each wave computes 2 image rows (2 x 32 pixels) x 128
+// output channels = 2 x 4 MFMA 32x32x16 blocks (128 accumulator VGPRs), 32 MFMAs per tap between barriers.
+//   config A: TH = 8,  waves 4 (rows) x 2 (channels), BN = 256   (Cout % 256 == 0)
+//   config B: TH = 16, waves 8 x 1,                  BN = 128   (Cout % 128 == 0)
+// LDS: patch rows are 128 B (64 channels); 16-byte chunk index XOR (pixel>>1)&7 -> conflict-free ds_read_b128 for any
+// tap shift, since a lane group always covers 16 consecutive-modulo-16 patch pixels.
+// Fused: nearest-x2 upsample of the input (patch gather), skip-concat (two sources), optional GroupNorm-apply
+// (+FiLM) + activation on the patch as it is written to LDS (zero padding stays zero), bias / per-sample bias /
+// activation / residual (optionally through a nearest-x2 upsample) / fp32 or 16-bit NHWC output in the epilogue.
+#include "common.h"
+#include "epilogue.h"
+#include "../../include/perceptor_hip.h"
+
+namespace {
+
+constexpr int PW = 34;
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// PRO: 0 none, else 1 + PMI_ACT_* of the fused GroupNorm-apply prologue.  EARLY: prefetch the next patch into registers
+// under the last tap's MFMAs (only when the register budget allows and there is no second workgroup to hide the latency).
+template <typename T, int WM, int WN, int PRO, bool EARLY>
+__global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(const pmi_igemm_args a) {
+  constexpr int TH = WM * 2;                           // each wave owns two image rows
+  constexpr int NT = WM * WN * 64;                     // threads per workgroup
+  constexpr int RPI = NT / 8;                          // tile rows staged per pass (8 threads x 16 B per 128-B row)
+  constexpr int BN = WN * 128;
+  constexpr int PP = (TH + 2) * PW;                    // patch pixels
+  constexpr int NPI = (PP + RPI - 1) / RPI;            // 16-byte patch chunks per thread
+  constexpr int NWI = BN / RPI;                        // 16-byte weight chunks per thread per tap
+  constexpr int PATCH_BYTES = PP * 128;
+  constexpr int WBYTES = BN * 128;
+  __shared__ __attribute__((aligned(16))) char smem[PATCH_BYTES + 2 * WBYTES];
+  char* const patch = smem;
+  char* const wbuf = smem + PATCH_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+
+  const int tiles_x = a.W / 32, tiles_y = a.H / TH, tiles_n = (a.N + BN - 1) / BN;
+  const int nimg = a.M / (a.H * a.W);
+  int logical = xcd_remap(blockIdx.x, nimg * tiles_y * tiles_x * tiles_n);
+  const int tn = logical % tiles_n; logical /= tiles_n;
+  const int tx = logical % tiles_x; logical /= tiles_x;
+  const int ty = logical % tiles_y;
+  const int img = logical / tiles_y;
+  const int y0 = ty * TH, x0 = tx * 32, n0 = tn * BN;
+
+  const int Cin = a.C0 + a.C1;
+  const int Hv = a.H, Wv = a.W;                         // conv runs on the (possibly upsampled) H x W grid
+  const u16* A0 = (const u16*)a.A0;
+  const u16* A1 = (const u16*)a.A1;
+  const u16* Bw = (const u16*)a.B;
+  const int sc = tid & 7;                              // 16-byte chunk (8 channels) this thread stages, fixed
+
+  // ---- patch staging plan: source pixel index per staged chunk (-1 = zero padding) ----
+  int poff[NPI];
+#pragma unroll
+  for (int i = 0; i < NPI; ++i) {
+    const int pp = (tid >> 3) + RPI * i;
+    int off = -1;
+    if (pp < PP) {
+      const int py = pp / PW, px = pp - py * PW;
+      int sy = y0 - 1 + py, sx = x0 - 1 + px;
+      if (sy >= 0 && sy < Hv && sx >= 0 && sx < Wv) {
+        if (a.up) { sy >>= 1; sx >>= 1; }
+        off = (img * a.Hin + sy) * a.Win + sx;
+      }
+    }
+    poff[i] = off;
+  }
+  int wrow[NWI];                                       // element offset of this thread's weight chunk (fits 31 bits: Cout*9*Cin)
+#pragma unroll
+  for (int i = 0; i < NWI; ++i) {
+    const int n = n0 + (tid >> 3) + RPI * i;
+    wrow[i] = n < a.N ? n * a.ldb + sc * 8 : -1;
+  }
+
+  uint4 pr[NPI], wr[NWI];
+  float ga[8], gb[8];
+  auto load_patch = [&](int chunk) {
+    const int ci = chunk * 64 + sc * 8;
+    const bool second = ci >= a.C0;
+    const u16* base = second ? A1 + (ci - a.C0) : A0 + ci;
+    const int ld = second ? a.lda1 : a.lda0;
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (poff[i] >= 0) v = *(const uint4*)(base + (int64_t)poff[i] * ld);
+      pr[i] = v;
+    }
+    if (PRO) {
+      const float* pa = a.pro_a + (int64_t)img * Cin + ci;
+      const float* pb = a.pro_b + (int64_t)img * Cin + ci;
+      *(float4*)ga = *(const float4*)pa; *(float4*)(ga + 4) = *(const float4*)(pa + 4);
+      *(float4*)gb = *(const float4*)pb; *(float4*)(gb + 4) = *(const float4*)(pb + 4);
+    }
+  };
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+      const int pp = (tid >> 3) + RPI * i;
+      if (pp < PP) {
+        uint4 v = pr[i];
+        if (PRO && poff[i] >= 0) {
+          float f[8];
+          unpack8<T>(v, f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = act_apply(f[e] * ga[e] + gb[e], PRO - 1);
+          v = pack8<T>(f);
+        }
+        *(uint4*)(patch + swz(pp, sc)) = v;
+      }
+    }
+  };
+  auto load_w = [&](int chunk, int tap) {
+    const int64_t koff = (int64_t)tap * Cin + chunk * 64;
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (wrow[i] >= 0) v = *(const uint4*)(Bw + (int64_t)wrow[i] + koff);
+      wr[i] = v;
+    }
+  };
+  auto store_w = [&](int buf) {
+    char* wb = wbuf + buf * WBYTES;
+#pragma unroll
+    for (int i = 0; i < NWI; ++i) *(uint4*)(wb + swz((tid >> 3) + RPI * i, sc)) = wr[i];
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nchunks = Cin / 64;
+  load_patch(0);
+  load_w(0, 0);
+  store_patch();
+  store_w(0);
+  __syncthreads();
+  int cur = 0;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const bool last_tap = tap == 8;
+      const bool more_chunks = chunk + 1 < nchunks;
+      const bool has_next = !last_tap || more_chunks;
+      if (has_next) load_w(last_tap ? chunk + 1 : chunk, last_tap ? 0 : tap + 1);
+      // Without a prologue the next patch is prefetched into registers under the MFMAs of the last tap.  With the fused
+      // GroupNorm prologue that would push the kernel over 256 VGPRs (spills), so the loads are issued after the MFMAs
+      // instead (one exposed load latency per 64-channel chunk = per 288 MFMAs).
+      if (EARLY && last_tap && more_chunks) load_patch(chunk + 1);
+      const int dy = tap / 3, dx = tap - dy * 3;        // patch row/col offset (tap - 1 + halo 1)
+      const char* wb = wbuf + cur * WBYTES;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int ch = kk * 2 + lhi;
+        uint4 xf[2], wf[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) xf[i] = *(const uint4*)(patch + swz((2 * wm + i + dy) * PW + l31 + dx, ch));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wf[j] = *(const uint4*)(wb + swz(wn * 128 + j * 32 + l31, ch));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma32(wf[j], xf[i], acc[i][j]);
+      }
+      if (has_next) store_w(cur ^ 1);
+      if (last_tap && more_chunks) {
+        if (!EARLY) load_patch(chunk + 1);
+        __syncthreads();          // every wave is done reading the current patch
+        store_patch();
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  // ---- epilogue: lane = pixel, registers = 4 consecutive output channels x 4 groups per 32x32 block ----
+  float* const stat = (float*)smem;            // [BN][2] per-channel (sum, sumsq) of this tile (LDS is free now)
+  if (a.stats) {
+    for (int c = tid; c < 2 * BN; c += NT) stat[c] = 0.f;
+    __syncthreads();
+  }
+  int64_t mpix[2], rrow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int y = y0 + 2 * wm + i, x = x0 + l31;
+    mpix[i] = ((int64_t)img * a.H + y) * a.W + x;
+    rrow[i] = mpix[i] * a.ldr;
+    if (a.R && a.res_up) rrow[i] = (((int64_t)img * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.ldr;
+  }
+  const float* nbp = a.nbias ? a.nbias + (int64_t)img * (a.ldnb ? a.ldnb : a.N) : nullptr;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * 128 + j * 32 + 4 * lhi + 8 * g;
+        if (n >= a.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * a.alpha;
+        if (a.bias) { const float4 b = *(const float4*)(a.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+        if (nbp) { const float4 b = *(const float4*)(nbp + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+        if (a.act != PMI_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
+        }
+        if (a.R) {
+          if (a.res_f32) {
+            const float4 r = *(const float4*)((const float*)a.R + rrow[i] + n);
+            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+          } else {
+            const uint2 r = *(const uint2*)((const u16*)a.R + rrow[i] + n);
+            v[0] += T::to_f((u16)(r.x & 0xffff)); v[1] += T::to_f((u16)(r.x >> 16));
+            v[2] += T::to_f((u16)(r.y & 0xffff)); v[3] += T::to_f((u16)(r.y >> 16));
+          }
+        }
+        const int64_t o = mpix[i] * a.ldd + n;
+        if (a.out_f32) *(float4*)((float*)a.D + o) = make_float4(v[0], v[1], v[2], v[3]);
+        else *(uint2*)((u16*)a.D + o) = pack4<T>(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ssum[4 * g + e] += v[e]; ssq[4 * g + e] += v[e] * v[e]; }
+      }
+    }
+    if (a.stats) stats_block_to_lds(ssum, ssq, stat, wn * 128 + j * 32, lane);
+  }
+  if (a.stats) {
+    __syncthreads();
+    float* o = a.stats + (((int64_t)img * a.stats_p + ty * tiles_x + tx) * a.N + n0) * 2;
+    for (int c = tid; c < 2 * BN; c += NT)
+      if (n0 + (c >> 1) < a.N) o[c] = stat[c];
+  }
+}
+
+template <typename T, int PRO>
+int launch_p(const pmi_igemm_args& a, hipStream_t s, int cfg) {
+  const int nimg = a.M / (a.H * a.W);
+  if (cfg == 0) {          // 8x32 px x 256 ch, 8 waves, one workgroup per CU
+    const int tiles = nimg * (a.H / 8) * (a.W / 32) * ((a.N + 255) / 256);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, 4, 2, PRO, PRO == 0>), dim3(tiles), dim3(512), 0, s, a);
+  } else if (cfg == 1) {   // 16x32 px x 128 ch, 8 waves
+    const int tiles = nimg * (a.H / 16) * (a.W / 32) * ((a.N + 127) / 128);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, 8, 1, PRO, PRO == 0>), dim3(tiles), dim3(512), 0, s, a);
+  } else {                 // 8x32 px x 128 ch, 4 waves, two workgroups per CU overlap each other's staging / epilogue
+    const int tiles = nimg * (a.H / 8) * (a.W / 32) * ((a.N + 127) / 128);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, 4, 1, PRO, false>), dim3(tiles), dim3(256), 0, s, a);
+  }
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+
+template <typename T>
+int launch_t(const pmi_igemm_args& a, hipStream_t s, int cfg) {
+  if (!a.pro_a) return launch_p<T, 0>(a, s, cfg);
+  switch (a.pro_act) {
+    case PMI_ACT_NONE: return launch_p<T, 1 + PMI_ACT_NONE>(a, s, cfg);
+    case PMI_ACT_RELU: return launch_p<T, 1 + PMI_ACT_RELU>(a, s, cfg);
+    case PMI_ACT_SILU: return launch_p<T, 1 + PMI_ACT_SILU>(a, s, cfg);
+    default: return PMI_ERR_ARG;
+  }
+}
+
+}  // namespace
+
+// Returns the config the halo kernel can run (0: 8x32 x 256ch, 1: 16x32 x 128ch) or -1 if the shape needs the generic kernel.
+static int g_force_cfg = -1;   // pmi_set_option(1, cfg): force a tile config where eligible (A/B benchmarking)
+void pmi_conv3x3_force_config(int cfg) { g_force_cfg = cfg; }
+
+// Returns the tile config the halo kernel runs for this shape (0: 8x32 px x 256 ch / 8 waves, 1: 16x32 x 128 / 8 waves,
+// 2: 8x32 x 128 / 4 waves x 2 workgroups per CU) or -1 if the shape needs the generic kernel.
+extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
+  if (a->taps != 9 || a->stride != 1 || a->batch > 1) return -1;
+  const int Cin = a->C0 + a->C1;
+  if ((Cin % 64) || (a->C0 % 64) || (a->W % 32) || (a->H % 8) || (a->N % 128)) return -1;
+  const bool ok0 = (a->N % 256) == 0 || a->N >= 256, ok1 = (a->H % 16) == 0;
+  if (g_force_cfg == 0 && ok0) return 0;
+  if (g_force_cfg == 1 && ok1) return 1;
+  if (g_force_cfg == 2) return 2;
+  // One 8-wave workgroup per CU: a grid well below 256 workgroups leaves CUs idle; such layers (<= 32x32 feature maps
+  // at batch 8) go to the generic kernel, whose 128x128 tiles (and split-K) fill the chip.
+  const int nimg = a->M / (a->H * a->W);
+  const int px_tiles8 = nimg * (a->H / 8) * (a->W / 32);
+  if ((a->N % 256) == 0) return px_tiles8 * (a->N / 256) >= 192 ? 0 : -1;
+  if (ok1 && (px_tiles8 / 2) * (a->N / 128) >= 192) return 1;
+  if (px_tiles8 * (a->N / 128) >= 384) return 2;
+  return -1;
+}
+
+int pmi_conv3x3_halo_launch(const pmi_igemm_args* a, int cfg, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  return a->dtype == PMI_DT_BF16 ? launch_t<BF16>(*a, s, cfg) : launch_t<F16>(*a, s, cfg);
+}

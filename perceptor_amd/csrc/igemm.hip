@@ -13,6 +13,7 @@
 // Global->LDS goes through registers (gathered addresses + zero fill for the conv halo);
 // the loads of k-tile t+1 are issued before the MFMAs of tile t and written after them.
 #include "common.h"
+#include "epilogue.h"
 #include "../../include/perceptor_hip.h"
 
 namespace {
@@ -128,14 +129,24 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (a.K + BK - 1) / BK;
+  const int nk_all = (a.K + BK - 1) / BK;
   const int l31 = lane & 31, lhi = lane >> 5;
+  // split-K (grid.z when batch <= 1): this workgroup reduces k-tiles [kt0, kt0 + nk) into its own fp32 slab
+  int kt0 = 0, nk = nk_all;
+  if (a.splitk > 1) {
+    const int per = (nk_all + a.splitk - 1) / a.splitk;
+    kt0 = blockIdx.z * per;
+    nk = min(per, nk_all - kt0);
+    if (KFAST) { tap_u = (kt0 * BK) / Cin; ci_u = kt0 * BK - tap_u * Cin; }
+  }
 
-  load_tile(0);
+  if (nk > 0) {
+  load_tile(kt0);
   store_tile(0);
+  }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tile(kt + 1);
+    if (kt + 1 < nk) load_tile(kt0 + kt + 1);
     const char* sa = smem + (kt & 1) * STAGE_BYTES;
     const char* sb = sa + TILE_BYTES;
 #pragma unroll
@@ -155,21 +166,53 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
     __syncthreads();
   }
 
+  if (a.splitk > 1) {   // raw fp32 partial sums; bias / activation / residual happen in splitk_reduce_kernel
+    float* slab = (float*)a.ws + (int64_t)blockIdx.z * a.M * a.N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + wr * 64 + i * 32 + l31;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wc * 64 + j * 32 + 4 * lhi + 8 * g;
+          if (n < a.N) *(float4*)(slab + (int64_t)m * a.N + n) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        }
+    }
+    return;
+  }
   // ---- epilogue: lane = pixel (col), registers = 4 consecutive output channels x 4 groups ----
+  float* const stat = (float*)smem;            // [BN][2] per-channel (sum, sumsq) of this tile (main loop is done with LDS)
+  if (a.stats) {
+    for (int c = tid; c < 2 * BN; c += 256) stat[c] = 0.f;
+    __syncthreads();
+  }
+  int64_t rrow[2];
+  const float* nbp[2];
+  int mrow[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + wr * 64 + i * 32 + l31;
-    if (m >= a.M) continue;
-    int64_t rrow = (int64_t)m * a.ldr;
-    if (a.R && a.res_up) {
+    mrow[i] = m;
+    rrow[i] = (int64_t)m * a.ldr;
+    if (a.R && a.res_up && m < a.M) {
       const int hw = a.H * a.W;
       const int img = m / hw, rem = m - img * hw;
       const int y = rem / a.W, x = rem - y * a.W;
-      rrow = ((int64_t)(img * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.ldr;
+      rrow[i] = ((int64_t)(img * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.ldr;
     }
-    const float* nbp = a.nbias ? a.nbias + (int64_t)(m / a.hw) * (a.ldnb ? a.ldnb : a.N) : nullptr;
+    nbp[i] = (a.nbias && m < a.M) ? a.nbias + (int64_t)(m / a.hw) * (a.ldnb ? a.ldnb : a.N) : nullptr;
+  }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < 2; ++j) {
+    float ssum[16], ssq[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mrow[i];
+      if (m >= a.M) continue;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = n0 + wc * 64 + j * 32 + 4 * lhi + 8 * g;
@@ -181,8 +224,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
           const float4 b = *(const float4*)(a.bias + n);
           v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         }
-        if (nbp) {
-          const float4 b = *(const float4*)(nbp + n);
+        if (nbp[i]) {
+          const float4 b = *(const float4*)(nbp[i] + n);
           v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
         }
         if (a.act != PMI_ACT_NONE) {
@@ -191,10 +234,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
         }
         if (a.R) {
           if (a.res_f32) {
-            const float4 r = *(const float4*)((const float*)a.R + offR + rrow + n);
+            const float4 r = *(const float4*)((const float*)a.R + offR + rrow[i] + n);
             v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
           } else {
-            const uint2 r = *(const uint2*)((const u16*)a.R + offR + rrow + n);
+            const uint2 r = *(const uint2*)((const u16*)a.R + offR + rrow[i] + n);
             v[0] += T::to_f((u16)(r.x & 0xffff)); v[1] += T::to_f((u16)(r.x >> 16));
             v[2] += T::to_f((u16)(r.y & 0xffff)); v[3] += T::to_f((u16)(r.y >> 16));
           }
@@ -202,15 +245,71 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
         const int64_t o = offD + (int64_t)m * a.ldd + n;
         if (a.out_f32) *(float4*)((float*)a.D + o) = make_float4(v[0], v[1], v[2], v[3]);
         else *(uint2*)((u16*)a.D + o) = pack4<T>(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ssum[4 * g + e] += v[e]; ssq[4 * g + e] += v[e] * v[e]; }
       }
     }
+    if (a.stats) stats_block_to_lds(ssum, ssq, stat, wc * 64 + j * 32, lane);
+  }
+  if (a.stats) {
+    __syncthreads();
+    const int img = m0 / a.hw, prow = (m0 - img * a.hw) / BM;
+    float* o = a.stats + ((int64_t)(img * a.stats_p + prow) * a.N + n0) * 2;
+    for (int c = tid; c < 2 * BN; c += 256)
+      if (n0 + (c >> 1) < a.N) o[c] = stat[c];
+  }
+}
+
+// sum the split-K slabs and apply the fused epilogue (bias, per-sample bias, activation, residual), 4 channels per thread
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const pmi_igemm_args a) {
+  const int n4 = a.N >> 2;
+  const int64_t total = (int64_t)a.M * n4;
+  const float* ws = (const float*)a.ws;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < a.splitk; ++z) {
+      const float4 p = *(const float4*)(ws + ((int64_t)z * a.M + m) * a.N + n);
+      s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    float v[4] = {s.x * a.alpha, s.y * a.alpha, s.z * a.alpha, s.w * a.alpha};
+    if (a.bias) { const float4 b = *(const float4*)(a.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+    if (a.nbias) {
+      const float4 b = *(const float4*)(a.nbias + (int64_t)(m / a.hw) * (a.ldnb ? a.ldnb : a.N) + n);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (a.act != PMI_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
+    }
+    if (a.R) {
+      int64_t rrow = (int64_t)m * a.ldr;
+      if (a.res_up) {
+        const int hw = a.H * a.W;
+        const int img = m / hw, rem = m - img * hw;
+        const int y = rem / a.W, x = rem - y * a.W;
+        rrow = ((int64_t)(img * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.ldr;
+      }
+      if (a.res_f32) {
+        const float4 r = *(const float4*)((const float*)a.R + rrow + n);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+      } else {
+        const uint2 r = *(const uint2*)((const u16*)a.R + rrow + n);
+        v[0] += T::to_f((u16)(r.x & 0xffff)); v[1] += T::to_f((u16)(r.x >> 16));
+        v[2] += T::to_f((u16)(r.y & 0xffff)); v[3] += T::to_f((u16)(r.y >> 16));
+      }
+    }
+    const int64_t o = (int64_t)m * a.ldd + n;
+    if (a.out_f32) *(float4*)((float*)a.D + o) = make_float4(v[0], v[1], v[2], v[3]);
+    else *(uint2*)((u16*)a.D + o) = pack4<T>(v[0], v[1], v[2], v[3]);
   }
 }
 
 template <typename T>
 int launch(const pmi_igemm_args& a, hipStream_t s) {
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  const dim3 grid(tiles, 1, a.batch > 1 ? a.batch : 1), block(256);
+  const dim3 grid(tiles, 1, a.batch > 1 ? a.batch : (a.splitk > 1 ? a.splitk : 1)), block(256);
   const bool conv = a.taps == 9 || a.up || a.stride == 2;
   const int Cin = a.C0 + a.C1;
   const bool kfast = (Cin % BK == 0) && (a.C0 % BK == 0);
@@ -222,10 +321,48 @@ int launch(const pmi_igemm_args& a, hipStream_t s) {
     else hipLaunchKernelGGL((igemm_kernel<T, false, false>), grid, block, 0, s, a);
   }
   PMI_CHECK_LAUNCH();
+  if (a.splitk > 1) {
+    const int64_t work = (int64_t)a.M * (a.N / 4);
+    const int blocks = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel<T>, dim3(blocks), dim3(256), 0, s, a);
+    PMI_CHECK_LAUNCH();
+  }
   return PMI_OK;
 }
 
 }  // namespace
+
+extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a);
+int pmi_conv3x3_halo_launch(const pmi_igemm_args* a, int cfg, void* stream);
+void pmi_conv3x3_force_config(int cfg);
+static int g_allow_halo = 1;
+// Split-K factor the generic kernel wants for this shape (1 = none): small-M layers (16x16 / 8x8 feature maps) otherwise
+// launch far fewer workgroups than the 256 CUs.  The caller then provides ws = S * M * N floats.
+extern "C" int pmi_igemm_splitk(const pmi_igemm_args* a) {
+  if (a->batch > 1 || (a->N & 3)) return 1;
+  if (g_allow_halo && pmi_conv3x3_halo_config(a) >= 0) return 1;
+  const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
+  const int nk = (a->K + BK - 1) / BK;
+  if (tiles >= 192 || nk < 16) return 1;
+  int s = 512 / tiles;
+  if (s > nk / 8) s = nk / 8;
+  if (s > 16) s = 16;
+  return s < 2 ? 1 : s;
+}
+
+extern "C" int pmi_igemm_stats_rows(const pmi_igemm_args* a) {
+  if (a->batch > 1 || a->splitk > 1) return 0;
+  const int halo = g_allow_halo ? pmi_conv3x3_halo_config(a) : -1;
+  if (halo >= 0) return (a->H / (halo == 1 ? 16 : 8)) * (a->W / 32);
+  if (a->hw > 0 && (a->hw % BM) == 0 && (a->M % a->hw) == 0) return a->hw / BM;
+  return 0;
+}
+
+extern "C" int pmi_set_option(int key, int value) {
+  if (key == 0) { const int old = g_allow_halo; g_allow_halo = value; return old; }
+  if (key == 1) { pmi_conv3x3_force_config(value); return 0; }
+  return PMI_ERR_ARG;
+}
 
 extern "C" int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream) {
   if (!a || !a->A0 || !a->B || !a->D) return PMI_ERR_ARG;
@@ -245,6 +382,11 @@ extern "C" int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream) {
   if ((conv || a->res_up) && (a->H <= 0 || a->W <= 0 || a->Hin <= 0 || a->Win <= 0 || a->M % (a->H * a->W))) return PMI_ERR_ARG;
   if (a->up && (a->H != 2 * a->Hin || a->W != 2 * a->Win)) return PMI_ERR_ARG;
   if (a->batch > 1 && a->batch_inner <= 0) return PMI_ERR_ARG;
+  const int halo = g_allow_halo ? pmi_conv3x3_halo_config(a) : -1;
+  if (a->pro_a && (!a->pro_b || halo < 0)) return PMI_ERR_ARG;
+  if (a->stats && a->stats_p != pmi_igemm_stats_rows(a)) return PMI_ERR_ARG;
+  if (a->splitk > 1 && (!a->ws || a->batch > 1 || halo >= 0 || (a->N & 3) || a->stats)) return PMI_ERR_ARG;
+  if (halo >= 0) return pmi_conv3x3_halo_launch(a, halo, stream);
   hipStream_t s = (hipStream_t)stream;
   return a->dtype == PMI_DT_BF16 ? launch<BF16>(*a, s) : launch<F16>(*a, s);
 }

@@ -41,41 +41,43 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const u16* __restrict__ x
     }
   }
   __syncthreads();
-  const int cpg = C / G;
-  for (int g = tid; g < G; g += 256) {
-    float s = 0.f, q = 0.f;
-    for (int j = 0; j < cpg; ++j) { s += s_sum[g * cpg + j]; q += s_sq[g * cpg + j]; }
-    float* o = ws + (((int64_t)n * nchunk + chunk) * G + g) * 2;
-    o[0] = s; o[1] = q;
-  }
+  float* o = ws + ((int64_t)n * nchunk + chunk) * C * 2;
+  for (int c = tid; c < C; c += 256) { o[2 * c] = s_sum[c]; o[2 * c + 1] = s_sq[c]; }
 }
 
 // ---- finalize: y = act(x * a[n][c] + b[n][c]) with affine and FiLM folded in -------------------
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ ws, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, const float* __restrict__ film,
-                                                          int film_ld, float* __restrict__ ca, float* __restrict__ cb,
-                                                          int HW, int C, int G, int nchunk, float eps) {
-  __shared__ float s_mean[256], s_rstd[256];
-  const int tid = threadIdx.x, n = blockIdx.x;
-  const int cpg = C / G;
-  for (int g = tid; g < G; g += 256) {
-    double s = 0.0, q = 0.0;
-    for (int k = 0; k < nchunk; ++k) {
-      const float* p = ws + (((int64_t)n * nchunk + k) * G + g) * 2;
-      s += p[0]; q += p[1];
-    }
-    const double cnt = (double)HW * cpg;
-    const double mean = s / cnt;
-    double var = q / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    s_mean[g] = (float)mean;
-    s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+// one workgroup per (sample, group); partials are per channel: s0[n][P0][C0][2] (+ s1 for the 2nd concat source)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ s0, int P0, int C0,
+                                                          const float* __restrict__ s1, int P1, int C1,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ film, int film_ld, float* __restrict__ ca,
+                                                          float* __restrict__ cb, int HW, int G, float eps) {
+  __shared__ double red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, n = blockIdx.x, g = blockIdx.y;
+  const int C = C0 + C1, cpg = C / G;
+  double s = 0.0, q = 0.0;
+  for (int j = 0; j < cpg; ++j) {
+    const int c = g * cpg + j;
+    const bool second = c >= C0;
+    const float* src = second ? s1 + ((int64_t)n * P1 * C1 + (c - C0)) * 2 : s0 + ((int64_t)n * P0 * C0 + c) * 2;
+    const int P = second ? P1 : P0, ld = (second ? C1 : C0) * 2;
+    for (int p = tid; p < P; p += 256) { s += src[(int64_t)p * ld]; q += src[(int64_t)p * ld + 1]; }
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+  if (lane == 0) { red[0][wid] = s; red[1][wid] = q; }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    const int g = c / cpg;
-    float a = s_rstd[g] * (gamma ? gamma[c] : 1.f);
-    float b = (beta ? beta[c] : 0.f) - s_mean[g] * a;
+  s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  const double cnt = (double)HW * cpg;
+  const double mean = s / cnt;
+  double var = q / cnt - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float fmean = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+  for (int j = tid; j < cpg; j += 256) {
+    const int c = g * cpg + j;
+    float a = rstd * (gamma ? gamma[c] : 1.f);
+    float b = (beta ? beta[c] : 0.f) - fmean * a;
     if (film) {
       const float sc = 1.f + film[(int64_t)n * film_ld + c], sh = film[(int64_t)n * film_ld + C + c];
       a *= sc; b = b * sc + sh;
@@ -153,12 +155,14 @@ extern "C" int pmi_gn_stats(const void* x, const void* x1, int C0, float* ws, in
   return PMI_OK;
 }
 
-extern "C" int pmi_gn_finalize(const float* ws, const float* gamma, const float* beta, const float* film, int film_ld,
-                               float* coef_a, float* coef_b, int N, int HW, int C, int G, int nchunk, float eps,
+extern "C" int pmi_gn_finalize(const float* s0, int P0, int C0, const float* s1, int P1, int C1, const float* gamma, const float* beta,
+                               const float* film, int film_ld, float* coef_a, float* coef_b, int N, int HW, int G, float eps,
                                pmi_stream_t s) {
-  if (!ws || !coef_a || !coef_b || N <= 0 || C <= 0 || G <= 0 || G > 256 || C % G) return PMI_ERR_ARG;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, (hipStream_t)s, ws, gamma, beta, film, film_ld, coef_a,
-                     coef_b, HW, C, G, nchunk, eps);
+  if (!s1) { C1 = 0; P1 = 0; }
+  const int C = C0 + C1;
+  if (!s0 || !coef_a || !coef_b || N <= 0 || C0 <= 0 || P0 <= 0 || G <= 0 || C % G || (s1 && P1 <= 0)) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N, G), dim3(256), 0, (hipStream_t)s, s0, P0, C0, s1, P1, C1, gamma, beta, film, film_ld,
+                     coef_a, coef_b, HW, G, eps);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }

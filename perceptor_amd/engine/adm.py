@@ -204,21 +204,29 @@ class AdmEngine:
     def _res(self, l: _Res, x, x1, emb):
         cfg, dt, w = self.cfg, self.dt, self.w
         g1, b1 = w[l.p + ".gn1"]
-        h = ops.group_norm(x, g1, b1, 32, dt, x1=x1, act=ACT_SILU, pool=l.down)
         ecols = 2 * l.cout if cfg.use_scale_shift_norm else l.cout
         e = emb[:, l.emb_off:l.emb_off + ecols]
+        nb = None if cfg.use_scale_shift_norm else e
         skip, skip1 = x, x1
         if l.down:
+            # SiLU(GN(x)) must be pooled AFTER the activation: streaming apply+pool kernel, then the conv
+            h = ops.group_norm(x, g1, b1, 32, dt, x1=x1, act=ACT_SILU, pool=True)
             skip = ops.avgpool2(x, dt)
-        h = ops.igemm(h, w[l.p + ".conv1"], up=l.up, nbias=None if cfg.use_scale_shift_norm else e)
+            h = ops.igemm(h, w[l.p + ".conv1"], nbias=nb, want_stats=True)
+        else:
+            # GroupNorm-apply + SiLU fused into the conv's patch staging (no activated copy in HBM)
+            ca, cb = ops.group_norm_coeffs(x, g1, b1, 32, dt, x1=x1)
+            h = ops.igemm(x, w[l.p + ".conv1"], a1=x1, up=l.up, nbias=nb, prologue=(ca, cb, ACT_SILU), want_stats=True)
         g2, b2 = w[l.p + ".gn2"]
         if cfg.use_scale_shift_norm:
-            h = ops.group_norm(h, g2, b2, 32, dt, film=e, film_ld=emb.stride(0), act=ACT_SILU)
+            ca, cb = ops.group_norm_coeffs(h, g2, b2, 32, dt, film=e, film_ld=emb.stride(0))
         else:
-            h = ops.group_norm(h, g2, b2, 32, dt, act=ACT_SILU)
+            ca, cb = ops.group_norm_coeffs(h, g2, b2, 32, dt)
         if l.cin != l.cout:
             skip = ops.igemm(skip, w[l.p + ".skip"], a1=skip1)
-        return ops.igemm(h, w[l.p + ".conv2"], residual=skip, res_up=l.up)
+        elif skip1 is not None:
+            raise NotImplementedError("identity skip over a concatenated input does not occur in the shipped configs")
+        return ops.igemm(h, w[l.p + ".conv2"], residual=skip, res_up=l.up, prologue=(ca, cb, ACT_SILU), want_stats=True)
 
     def _attn(self, l: _Attn, x):
         dt, w = self.dt, self.w
@@ -227,20 +235,23 @@ class AdmEngine:
         hn = ops.group_norm(x, g, b, 32, dt)
         qkv = ops.igemm(hn.view(n * hh * ww, c), w[l.p + ".qkv"])
         a = ops.attention(qkv.view(n, hh * ww, 3 * c), l.heads, 1 if self.cfg.use_new_attention_order else 0, dt)
-        out = ops.igemm(a.view(n * hh * ww, c), w[l.p + ".proj"], residual=x.view(n * hh * ww, c))
-        return out.view(n, hh, ww, c)
+        out = ops.igemm(a.view(n * hh * ww, c), w[l.p + ".proj"], residual=x.view(n * hh * ww, c), want_stats=True, hw=hh * ww)
+        o4 = out.view(n, hh, ww, c)
+        if hasattr(out, "_pmi_stats"):
+            o4._pmi_stats = out._pmi_stats
+        return o4
 
     def _run(self, layers, h, h1, emb):
         for l in layers:
             if isinstance(l, tuple):
-                h = ops.igemm(h, self.w[l[1]])
+                h = ops.igemm(h, self.w[l[1]], want_stats=True)
             elif isinstance(l, _Res):
                 h = self._res(l, h, h1, emb)
             elif isinstance(l, _Attn):
                 h = self._attn(l, h)
             elif isinstance(l, _Resample):
                 if self.cfg.conv_resample:
-                    h = ops.igemm(h, self.w[l.p], up=l.up, stride=1 if l.up else 2)
+                    h = ops.igemm(h, self.w[l.p], up=l.up, stride=1 if l.up else 2, want_stats=True)
                 else:
                     raise NotImplementedError("conv_resample=False is not used by the shipped configs")
             h1 = None
@@ -271,8 +282,8 @@ class AdmEngine:
         for layers in self.out:
             h = self._run(layers, h, hs.pop(), emb)
         g, b = self.gn_out
-        h = ops.group_norm(h, g, b, 32, dt, act=ACT_SILU)
-        y = ops.igemm(h, self.conv_out, out_f32=True)
+        ca, cb = ops.group_norm_coeffs(h, g, b, 32, dt)
+        y = ops.igemm(h, self.conv_out, out_f32=True, prologue=(ca, cb, ACT_SILU))
         co = out_channels or cfg.out_channels
         out = torch.empty((n, co, hh, ww), dtype=torch.float32, device=dev)
         call("pmi_finish_output", ptr(y), y.shape[-1], ptr(out), n, hh, ww, co)

@@ -15,6 +15,17 @@ from .. import _hip
 from .._hip import ACT_NONE, IgemmArgs, call, ptr
 
 
+HALO_ENABLED = True
+SPLITK_ENABLED = True
+
+
+def set_halo(enabled: bool) -> None:
+    """A/B switch: route conv3x3 through the LDS-halo kernel (default) or the generic implicit-GEMM kernel."""
+    global HALO_ENABLED
+    HALO_ENABLED = bool(enabled)
+    _hip.lib().pmi_set_option(0, int(enabled))
+
+
 # bench.py sets this to a list to time every conv3x3 launch with HIP events on the launch stream
 KERNEL_EVENTS = None
 
@@ -53,8 +64,12 @@ class PackedLinear:
 
 def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
           act: int = ACT_NONE, up: bool = False, stride: int = 1, res_up: bool = False, nbias: Optional[torch.Tensor] = None,
-          out_f32: bool = False, out: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
-    """Convolution (a0 is [N,H,W,C]) or linear (a0 is [M,C]) through pmi_igemm."""
+          out_f32: bool = False, out: Optional[torch.Tensor] = None, alpha: float = 1.0, prologue=None,
+          want_stats: bool = False, hw: Optional[int] = None) -> torch.Tensor:
+    """Convolution (a0 is [N,H,W,C]) or linear (a0 is [M,C]) through pmi_igemm.
+
+    prologue = (coef_a [N,Cin], coef_b [N,Cin], act): fused GroupNorm-apply(+FiLM)+activation on the conv input
+    (LDS-halo conv3x3 kernel only); when the shape is not eligible the apply kernel runs first."""
     dt = lin.dt
     conv = a0.ndim == 4
     c0 = a0.shape[-1]
@@ -72,7 +87,7 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
     else:
         assert lin.taps == 1 and not up and stride == 1
         m = a0.shape[0]
-        a.hw = 1
+        a.hw = hw or 1
         oshape = (m, lin.n_p)
     if out is None:
         out = _empty(oshape, torch.float32 if out_f32 else _hip.TORCH_DTYPE[dt], a0.device)
@@ -90,6 +105,27 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
     a.ldnb = nbias.stride(0) if nbias is not None else 0
     a.batch, a.batch_inner = 1, 1
     a.dtype = dt
+    if prologue is not None:
+        ca, cb, pact = prologue
+        if HALO_ENABLED and _hip.lib().pmi_conv3x3_halo_config(C.byref(a)) >= 0:
+            a.pro_a, a.pro_b, a.pro_act = ptr(ca), ptr(cb), pact
+        else:   # not eligible: materialise act(x*a+b) with the streaming kernel, then convolve
+            n_, h_, w_, _ = a0.shape
+            y = _empty((n_, h_, w_, c0 + c1), a0.dtype, a0.device)
+            call("pmi_gn_apply", ptr(a0), ptr(a1), c0, ptr(ca), ptr(cb), None, ptr(y), n_, h_, w_, c0 + c1, pact, 0, dt)
+            a.A0, a.A1, a.C0, a.C1, a.lda0, a.lda1 = ptr(y), None, c0 + c1, 0, c0 + c1, 0
+            a0 = y
+    if SPLITK_ENABLED:
+        sk = _hip.lib().pmi_igemm_splitk(C.byref(a))
+        if sk > 1:   # few output tiles, long K: split the reduction over grid.z into fp32 slabs
+            ws = _empty((sk, m, lin.n_p), torch.float32, a0.device)
+            a.ws, a.splitk = ptr(ws), sk
+    if want_stats:
+        rows = _hip.lib().pmi_igemm_stats_rows(C.byref(a))
+        if rows > 0:   # fused per-channel (sum, sumsq) of the output for the next GroupNorm
+            st = _empty((m // a.hw, rows, lin.n_p, 2), torch.float32, a0.device)
+            a.stats, a.stats_p = ptr(st), rows
+            out._pmi_stats = (st, rows)
     if KERNEL_EVENTS is not None and lin.taps == 9:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -122,21 +158,40 @@ def bgemm(A: torch.Tensor, B: torch.Tensor, D: torch.Tensor, *, M: int, N: int, 
     return D
 
 
+def _gn_coeffs(x, x1, gamma, beta, groups, dt, film, film_ld, eps):
+    n, h, w, c0 = x.shape
+    c1 = x1.shape[-1] if x1 is not None else 0
+    c, hw, dev = c0 + c1, h * w, x.device
+    ca = _empty((n, c), torch.float32, dev)
+    cb = _empty((n, c), torch.float32, dev)
+    st0 = getattr(x, "_pmi_stats", None)
+    st1 = getattr(x1, "_pmi_stats", None) if x1 is not None else None
+    if st0 is not None and (x1 is None or st1 is not None):
+        # statistics came out of the producing kernels' epilogues: no pass over the activations at all
+        call("pmi_gn_finalize", ptr(st0[0]), st0[1], c0, ptr(st1[0]) if st1 else None, st1[1] if st1 else 0, c1,
+             ptr(gamma), ptr(beta), ptr(film), film_ld, ptr(ca), ptr(cb), n, hw, groups, eps)
+        return ca, cb
+    nchunk = max(1, min(hw // 64, (1024 + n - 1) // n))
+    ws = _empty((n, nchunk, c, 2), torch.float32, dev)
+    call("pmi_gn_stats", ptr(x), ptr(x1), c0, ptr(ws), n, hw, c, groups, nchunk, dt)
+    call("pmi_gn_finalize", ptr(ws), nchunk, c, None, 0, 0, ptr(gamma), ptr(beta), ptr(film), film_ld, ptr(ca), ptr(cb), n, hw, groups, eps)
+    return ca, cb
+
+
+def group_norm_coeffs(x: torch.Tensor, gamma, beta, groups: int, dt: int, *, x1: Optional[torch.Tensor] = None,
+                      film: Optional[torch.Tensor] = None, film_ld: int = 0, eps: float = 1e-5):
+    """Per-(sample, channel) coefficients (a, b) with norm(x)*gamma+beta[FiLM] = x*a+b (no apply pass)."""
+    return _gn_coeffs(x, x1, gamma, beta, groups, dt, film, film_ld, eps)
+
+
 def group_norm(x: torch.Tensor, gamma, beta, groups: int, dt: int, *, x1: Optional[torch.Tensor] = None,
                film: Optional[torch.Tensor] = None, film_ld: int = 0, residual: Optional[torch.Tensor] = None,
                act: int = ACT_NONE, pool: bool = False, eps: float = 1e-5) -> torch.Tensor:
-    """GroupNorm over the channel-concat of x (and x1) -> act(norm * gamma + beta [FiLM]) [-> 2x2 avg pool]."""
+    """GroupNorm over the channel-concat of x (and x1) -> act(norm * gamma + beta [FiLM]) [-> 2x2 avg pool] [+ residual]."""
     n, h, w, c0 = x.shape
     c = c0 + (x1.shape[-1] if x1 is not None else 0)
-    hw = h * w
-    nchunk = max(1, min(hw // 64, (1024 + n - 1) // n))
-    dev = x.device
-    ws = _empty((n, nchunk, groups, 2), torch.float32, dev)
-    ca = _empty((n, c), torch.float32, dev)
-    cb = _empty((n, c), torch.float32, dev)
-    call("pmi_gn_stats", ptr(x), ptr(x1), c0, ptr(ws), n, hw, c, groups, nchunk, dt)
-    call("pmi_gn_finalize", ptr(ws), ptr(gamma), ptr(beta), ptr(film), film_ld, ptr(ca), ptr(cb), n, hw, c, groups, nchunk, eps)
-    y = _empty((n, h // 2, w // 2, c) if pool else (n, h, w, c), x.dtype, dev)
+    ca, cb = _gn_coeffs(x, x1, gamma, beta, groups, dt, film, film_ld, eps)
+    y = _empty((n, h // 2, w // 2, c) if pool else (n, h, w, c), x.dtype, x.device)
     call("pmi_gn_apply", ptr(x), ptr(x1), c0, ptr(ca), ptr(cb), ptr(residual), ptr(y), n, h, w, c, act, int(pool), dt)
     return y
 

@@ -46,18 +46,40 @@ def _check(got, ref, dtype, extra=1.0):
     dict(n=1, h=16, w=16, cin=64, cout=72, k=3, stride=2),
     dict(n=2, h=8, w=8, cin=128, cout=256, k=1),
     dict(n=1, h=32, w=32, cin=128, cout=6, k=3, f32=True),  # output conv: 6 channels padded to 8, fp32 out
+    # LDS-halo conv3x3 kernel (W % 32 == 0, Cin % 64 == 0): both tile configs, borders, concat, up, residual-up
+    dict(n=2, h=16, w=32, cin=64, cout=128, k=3, force_cfg=1),
+    dict(n=1, h=8, w=64, cin=128, cout=256, k=3, force_cfg=0),
+    dict(n=2, h=16, w=32, cin=192, cout=256, k=3, split=128, force_cfg=0),
+    dict(n=1, h=8, w=16, cin=64, cout=128, k=3, up=True, force_cfg=1),
+    dict(n=1, h=16, w=32, cin=64, cout=384, k=3, res_up=True, force_cfg=2),
+    dict(n=1, h=32, w=32, cin=128, cout=128, k=3, prologue=True, force_cfg=1),
+    dict(n=2, h=8, w=32, cin=64, cout=256, k=3, prologue=True, force_cfg=0),
+    dict(n=2, h=8, w=32, cin=128, cout=128, k=3, prologue=True, force_cfg=2),
+    dict(n=8, h=64, w=64, cin=64, cout=256, k=3, prologue=True),           # enough tiles for the halo kernel by itself
+    dict(n=2, h=16, w=16, cin=512, cout=128, k=3),                        # few tiles, long K: split-K slabs + reduce
+    dict(n=1, h=8, w=8, cin=1024, cout=256, k=3, res_up=False),
 ])
 def test_igemm_conv(case, dtype):
     from perceptor_amd.engine import ops
+    from perceptor_amd import _hip
     from perceptor_amd._hip import dtype_code
     dev = _dev()
+    # small unit shapes would otherwise be routed to the generic kernel (grid-fill heuristic): force the halo tile configs
+    _hip.lib().pmi_set_option(1, case.get("force_cfg", -1))
     g = torch.Generator().manual_seed(0)
     n, h, w, cin, cout, k = (case[z] for z in ("n", "h", "w", "cin", "cout", "k"))
     x = _r(torch.randn(n, cin, h, w, generator=g), dtype)
     wt = _r(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, dtype)
     b = torch.randn(cout, generator=g) * 0.1
     up, stride = case.get("up", False), case.get("stride", 1)
-    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    pro = None
+    if case.get("prologue"):
+        pa, pb = 1 + 0.3 * torch.randn(n, cin, generator=g), 0.3 * torch.randn(n, cin, generator=g)
+        pro = (pa.to(dev), pb.to(dev), 2)
+        x_conv = _r(F.silu(x * pa[:, :, None, None] + pb[:, :, None, None]), dtype)   # the kernel rounds the activated patch to 16 bit
+    else:
+        x_conv = x
+    xin = F.interpolate(x_conv, scale_factor=2, mode="nearest") if up else x_conv
     ref = F.conv2d(xin, wt, b, stride=stride, padding=k // 2)
     res = _r(torch.randn_like(ref), dtype)
     res_in = res
@@ -71,7 +93,7 @@ def test_igemm_conv(case, dtype):
     a0, a1 = xs, None
     if "split" in case:
         a0, a1 = xs[..., :case["split"]].contiguous(), xs[..., case["split"]:].contiguous()
-    out = ops.igemm(a0, lin, a1=a1, residual=_nhwc(res_in, dtype).to(dev) if not case.get("f32") else None,
+    out = ops.igemm(a0, lin, a1=a1, prologue=pro, residual=_nhwc(res_in, dtype).to(dev) if not case.get("f32") else None,
                     act=1, up=up, stride=stride, res_up=case.get("res_up", False), out_f32=case.get("f32", False))
     if case.get("f32"):
         ref = ref - res
@@ -79,6 +101,7 @@ def test_igemm_conv(case, dtype):
         assert float((got - ref).abs().max()) <= 2e-5 * (float(ref.abs().max()) + 1)
     else:
         _check(out[..., :cout].permute(0, 3, 1, 2).cpu(), ref, dtype)
+    _hip.lib().pmi_set_option(1, -1)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -201,3 +224,35 @@ def test_sampler_updates_match_golden():
     call("pmi_ddim_v_step", ptr(g["img"]), ptr(g["eps"]), ptr(vaf), ptr(vsf), ptr(vat), ptr(vst), ptr(nxt), ptr(den), 2, 3 * 16 * 16)
     assert float((nxt - g["v_step"]).abs().max()) < 2e-6 * float(g["v_step"].abs().max() + 1)
     assert float((den - g["v_denoised"]).abs().max()) < 2e-6 * float(g["v_denoised"].abs().max() + 1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [dict(h=16, w=32, cin=64, cout=256, force_cfg=0), dict(h=32, w=32, cin=64, cout=128, force_cfg=1), dict(h=16, w=16, cin=64, cout=192),
+                                  dict(h=8, w=16, cin=64, cout=64, k=1)])
+def test_fused_output_statistics_feed_groupnorm(case, dtype):
+    """conv epilogue statistics (halo + generic kernels) -> GroupNorm coefficients == standalone statistics pass,
+    also for a concat of two producers with a group that spans both."""
+    from perceptor_amd.engine import ops
+    from perceptor_amd._hip import dtype_code
+    dev = _dev()
+    dt = dtype_code(dtype)
+    g = torch.Generator().manual_seed(7)
+    n, h, w, cin, cout, k = 3, case["h"], case["w"], case["cin"], case["cout"], case.get("k", 3)
+    x = _nhwc(torch.randn(n, cin, h, w, generator=g), dtype).to(dev)
+    lin = ops.PackedLinear(torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5, torch.randn(cout, generator=g), dt, dev)
+    lin2 = ops.PackedLinear(torch.randn(64, cin, k, k, generator=g) / (cin * k * k) ** 0.5, torch.randn(64, generator=g), dt, dev)
+    from perceptor_amd import _hip
+    _hip.lib().pmi_set_option(1, case.get("force_cfg", -1))
+    y = ops.igemm(x, lin, want_stats=True)
+    _hip.lib().pmi_set_option(1, -1)
+    y2 = ops.igemm(x, lin2, want_stats=True)
+    assert hasattr(y, "_pmi_stats") and hasattr(y2, "_pmi_stats")
+    gamma, beta = (1 + 0.1 * torch.randn(cout + 64, generator=g)).to(dev), (0.1 * torch.randn(cout + 64, generator=g)).to(dev)
+    a_f, b_f = ops.group_norm_coeffs(y, gamma, beta, 32, dt, x1=y2)                       # fused statistics, concat of two producers
+    yc, y2c = y.clone(), y2.clone()                                                         # clones carry no statistics
+    a_s, b_s = ops.group_norm_coeffs(yc, gamma, beta, 32, dt, x1=y2c)                     # standalone statistics kernel
+    ref = F.group_norm(torch.cat([y, y2], -1).float().permute(0, 3, 1, 2), 32, gamma, beta, eps=1e-5)
+    got = (torch.cat([y, y2], -1).float() * a_f[:, None, None, :] + b_f[:, None, None, :]).permute(0, 3, 1, 2)
+    # statistics of the un-rounded fp32 outputs vs of the stored 16-bit tensor: differ by rounding noise only
+    assert float((a_f - a_s).abs().max()) <= 4 * ULP[dtype] * float(a_s.abs().max())
+    assert float((got - ref).abs().max()) <= 4 * ULP[dtype] * float(ref.abs().max())
