@@ -281,6 +281,8 @@ int launch_t(const pmi_igemm_args& a, hipStream_t s, int cfg) {
 // Returns the config the halo kernel can run (0: 8x32 x 256ch, 1: 16x32 x 128ch) or -1 if the shape needs the generic kernel.
 static int g_force_cfg = -1;   // pmi_set_option(1, cfg): force a tile config where eligible (A/B benchmarking)
 void pmi_conv3x3_force_config(int cfg) { g_force_cfg = cfg; }
+void pmi_conv3x3_use_glds(int) {}      // experiments measured and dropped: direct-to-LDS weights, persistent tiles
+void pmi_conv3x3_persistent(int) {}
 
 // Returns the tile config the halo kernel runs for this shape (0: 8x32 px x 256 ch / 8 waves, 1: 16x32 x 128 / 8 waves,
 // 2: 8x32 x 128 / 4 waves x 2 workgroups per CU) or -1 if the shape needs the generic kernel.

@@ -335,6 +335,8 @@ int launch(const pmi_igemm_args& a, hipStream_t s) {
 extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a);
 int pmi_conv3x3_halo_launch(const pmi_igemm_args* a, int cfg, void* stream);
 void pmi_conv3x3_force_config(int cfg);
+void pmi_conv3x3_use_glds(int v);
+void pmi_conv3x3_persistent(int v);
 static int g_allow_halo = 1;
 // Split-K factor the generic kernel wants for this shape (1 = none): small-M layers (16x16 / 8x8 feature maps) otherwise
 // launch far fewer workgroups than the 256 CUs.  The caller then provides ws = S * M * N floats.
@@ -361,6 +363,8 @@ extern "C" int pmi_igemm_stats_rows(const pmi_igemm_args* a) {
 extern "C" int pmi_set_option(int key, int value) {
   if (key == 0) { const int old = g_allow_halo; g_allow_halo = value; return old; }
   if (key == 1) { pmi_conv3x3_force_config(value); return 0; }
+  if (key == 2) { pmi_conv3x3_use_glds(value); return 0; }
+  if (key == 3) { pmi_conv3x3_persistent(value); return 0; }
   return PMI_ERR_ARG;
 }
 
