@@ -114,6 +114,7 @@ int pmi_prep_input(const float* img, const float* planes, int nplanes, void* x, 
 int pmi_finish_output(const float* y, int ld, float* out, int N, int H, int W, int cout, pmi_stream_t s);
 int pmi_avgpool2(const void* x, void* y, int N, int H, int W, int C, int dtype, pmi_stream_t s);            /* nn.AvgPool2d(2) */
 int pmi_upsample_bilinear2(const void* x, void* y, int N, int H, int W, int C, int dtype, pmi_stream_t s);  /* align_corners=False */
+int pmi_upsample_nearest2(const void* x, void* y, int N, int H, int W, int C, pmi_stream_t s);              /* nn.Upsample(2, 'nearest'), 16-bit NHWC */
 /* nn.py:101-118 sinusoidal embedding [cos|sin] -> 16-bit [N][dim] */
 int pmi_timestep_embedding(const float* t, void* out, int N, int dim, float max_period, int dtype, pmi_stream_t s);
 /* yfcc_2.py:41-49 Fourier features: out[n] = [cos(2 pi t w_j) | sin(2 pi t w_j)] fp32 */

@@ -136,6 +136,21 @@ def gen_vdiff():
     save("vdiff_cc12m_1_64", x=x, t=t, clip_embed=ce, y_sub=y[:, :, ::2, ::2].contiguous(), y_mom=moments(y))
 
 
+def gen_vdiff2():
+    y1 = R.ref("models.velocity_diffusion.yfcc_1")
+    wa = R.ref("models.velocity_diffusion.wikiart_256")
+    # wikiart has no normalisation anywhere (not even in attention): unit-gain random weights overflow fp16, so gain 0.6
+    for name, cls, res, t, seed, gain in (("yfcc_1", y1.YFCC1Model, 128, 0.45, 44, 1.0), ("wikiart", wa.WikiArt256Model, 64, 0.6, 45, 0.6)):
+        m = cls().eval()
+        m.load_state_dict(synth_like(m.state_dict(), 0, gain))
+        x = seeded_noise((1, 3, res, res), seed)
+        tt = torch.tensor([t])
+        with torch.no_grad():
+            y = m(x, tt)
+        save(f"vdiff_{name}_{res}", x=x, t=tt, y_sub=y[:, :, ::2, ::2].contiguous(), y_mom=moments(y))
+        del m
+
+
 def gen_clip():
     rz = R.ref("transforms.resize.resize_right")
     ru = R.ref("models.ruclip.model")

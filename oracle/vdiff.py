@@ -72,6 +72,29 @@ def cc12m1_spec():
         ("res", cs[0], cs[0], cs[0], False), ("res", cs[0], cs[0], 3, True)])
 
 
+def yfcc1_spec():   # yfcc_1.py:78-336
+    c = 128
+    cs = [c, c, c * 2, c * 2, c * 4, c * 4, c * 8, c * 8]
+    inner = _level_spec(cs, 1, None, 5, 4, 8)
+    return dict(name="yfcc_1", shape=(3, 512, 512), cond=False, cs=cs, net=[
+        ("res", 3 + 16, cs[0], cs[0], False)] + [("res", cs[0], cs[0], cs[0], False)] * 3 + [
+        ("skip", inner),
+        ("res", cs[0] * 2, cs[0], cs[0], False), ("res", cs[0], cs[0], cs[0], False), ("res", cs[0], cs[0], cs[0], False),
+        ("res", cs[0], cs[0], 3, True)])
+
+
+def wikiart_spec():  # wikiart_256.py:105-291
+    c = 128
+    cs = [c // 2, c, c * 2, c * 2, c * 4, c * 4, c * 8]
+    inner = _level_spec(cs, 1, None, 4, 4, 8)
+    return dict(name="wikiart", shape=(3, 256, 256), cond=False, cs=cs, head_dim=128, attn_norm=False, up_mode="nearest",
+                t_input="log_snr", skip_first=True, net=[
+        ("res", 3 + 16, cs[0], cs[0], False)] + [("res", cs[0], cs[0], cs[0], False)] * 3 + [
+        ("skip", inner),
+        ("res", cs[0] * 2, cs[0], cs[0], False), ("res", cs[0], cs[0], cs[0], False), ("res", cs[0], cs[0], cs[0], False),
+        ("res", cs[0], cs[0], 3, True)])
+
+
 def tiny_spec(cond: bool, c: int = 64):
     """Small net of the same family (2 levels + attention) for fast full-tensor parity."""
     cs = [c, c * 2, c * 2]
@@ -105,7 +128,8 @@ def state_dict_shapes(spec) -> Dict[str, Tuple[int, ...]]:
                     S[p + ".skip.weight"] = (cout, cin, 1, 1)
             elif l[0] == "attn":
                 c = l[1]
-                S[p + ".norm.weight"] = (c,); S[p + ".norm.bias"] = (c,)
+                if spec.get("attn_norm", True):
+                    S[p + ".norm.weight"] = (c,); S[p + ".norm.bias"] = (c,)
                 S[p + ".qkv_proj.weight"] = (3 * c, c, 1, 1); S[p + ".qkv_proj.bias"] = (3 * c,)
                 S[p + ".out_proj.weight"] = (c, c, 1, 1); S[p + ".out_proj.bias"] = (c,)
             elif l[0] == "skip":
@@ -131,10 +155,10 @@ def fourier_features(t, weight):
 
 
 def _attn(sd, p, x, heads):
-    # yfcc_2.py:62-70
+    # yfcc_2.py:62-70 ; wikiart_256.py:61-77 has no norm
     n, c, h, w = x.shape
-    qkv = F.conv2d(F.group_norm(x, 1, sd[p + ".norm.weight"], sd[p + ".norm.bias"], eps=1e-5),
-                   sd[p + ".qkv_proj.weight"], sd[p + ".qkv_proj.bias"])
+    xn = F.group_norm(x, 1, sd[p + ".norm.weight"], sd[p + ".norm.bias"], eps=1e-5) if (p + ".norm.weight") in sd else x
+    qkv = F.conv2d(xn, sd[p + ".qkv_proj.weight"], sd[p + ".qkv_proj.bias"])
     qkv = qkv.view(n, heads * 3, c // heads, h * w).transpose(2, 3)
     q, k, v = qkv.chunk(3, dim=1)
     s = k.shape[3] ** -0.25
@@ -166,19 +190,22 @@ def _res(sd, p, x, l, cond_vec):
     return h + s
 
 
-def _walk(sd, layers, prefix, x, cond_vec):
+def _walk(sd, layers, prefix, x, cond_vec, head_dim=64, up_mode="bilinear", skip_first=False):
     for idx, l in enumerate(layers):
         p = f"{prefix}.{idx}"
         if l[0] == "res":
             x = _res(sd, p, x, l, cond_vec)
         elif l[0] == "attn":
-            x = _attn(sd, p, x, l[1] // 64)
+            x = _attn(sd, p, x, l[1] // head_dim)
         elif l[0] == "down":
             x = F.avg_pool2d(x, 2)
         elif l[0] == "up":
-            x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+            x = F.interpolate(x, scale_factor=2, mode="nearest") if up_mode == "nearest" else \
+                F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
         elif l[0] == "skip":
-            x = torch.cat([_walk(sd, l[1], p + ".main", x, cond_vec), x], dim=1)
+            inner = _walk(sd, l[1], p + ".main", x, cond_vec, head_dim, up_mode, skip_first)
+            # yfcc_2.py:37-38 cat([main, skip]); wikiart_256.py:86-87 cat([skip, main])
+            x = torch.cat([x, inner], dim=1) if skip_first else torch.cat([inner, x], dim=1)
     return x
 
 
@@ -198,6 +225,10 @@ def mapping_cond(sd, t, clip_embed):
 def vdiff_forward(sd, spec, x, t, clip_embed=None):
     sd = {k: v.float() for k, v in sd.items()}
     cond_vec = mapping_cond(sd, t, clip_embed) if spec["cond"] else None
-    te = fourier_features(t, sd["timestep_embed.weight"])
+    tf = t.float()
+    if spec.get("t_input") == "log_snr":   # wikiart_256.py:288-292
+        tf = torch.log(torch.cos(tf * math.pi / 2) ** 2 / torch.sin(tf * math.pi / 2) ** 2)
+    te = fourier_features(tf, sd["timestep_embed.weight"])
     planes = te[..., None, None].repeat(1, 1, x.shape[2], x.shape[3])
-    return _walk(sd, spec["net"], "net", torch.cat([x.float(), planes], dim=1), cond_vec)
+    return _walk(sd, spec["net"], "net", torch.cat([x.float(), planes], dim=1), cond_vec,
+                 spec.get("head_dim", 64), spec.get("up_mode", "bilinear"), spec.get("skip_first", False))

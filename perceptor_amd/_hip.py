@@ -62,6 +62,7 @@ _PROTOS = {
     "pmi_finish_output": ([_P, _I, _P, _I, _I, _I, _I, _P],),
     "pmi_avgpool2": ([_P, _P, _I, _I, _I, _I, _I, _P],),
     "pmi_upsample_bilinear2": ([_P, _P, _I, _I, _I, _I, _I, _P],),
+    "pmi_upsample_nearest2": ([_P, _P, _I, _I, _I, _I, _P],),
     "pmi_timestep_embedding": ([_P, _P, _I, _I, _F, _I, _P],),
     "pmi_fourier_features": ([_P, _P, _P, _I, _I, _P],),
     "pmi_cast_f32_to_16": ([_P, _P, _L, _I, _I, _P],),

@@ -24,9 +24,12 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((ch
 
 // PRO: 0 none, else 1 + PMI_ACT_* of the fused GroupNorm-apply prologue.  EARLY: prefetch the next patch into registers
 // under the last tap's MFMAs (only when the register budget allows and there is no second workgroup to hide the latency).
-template <typename T, int WM, int WN, int PRO, bool EARLY>
-__global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(const pmi_igemm_args a) {
-  constexpr int TH = WM * 2;                           // each wave owns two image rows
+// XB: image rows (32-pixel MFMA blocks) per wave.  XB = 2 with 8 waves (two waves per SIMD, 256 registers each) or XB = 4
+// with 4 waves (ONE wave per SIMD owning the whole 512-register file: 256 accumulators, 0.5 instead of 0.75 LDS fragment
+// reads per MFMA, nothing to arbitrate on the SIMD).
+template <typename T, int WM, int WN, int PRO, bool EARLY, int XB = 2>
+__global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_kernel(const pmi_igemm_args a) {
+  constexpr int TH = WM * XB;                          // image rows per tile
   constexpr int NT = WM * WN * 64;                     // threads per workgroup
   constexpr int RPI = NT / 8;                          // tile rows staged per pass (8 threads x 16 B per 128-B row)
   constexpr int BN = WN * 128;
@@ -134,9 +137,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(const pmi_ig
     for (int i = 0; i < NWI; ++i) *(uint4*)(wb + swz((tid >> 3) + RPI * i, sc)) = wr[i];
   };
 
-  f32x16 acc[2][4];
+  f32x16 acc[XB][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < XB; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -165,13 +168,13 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(const pmi_ig
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int ch = kk * 2 + lhi;
-        uint4 xf[2], wf[4];
+        uint4 xf[XB], wf[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) xf[i] = *(const uint4*)(patch + swz((2 * wm + i + dy) * PW + l31 + dx, ch));
+        for (int i = 0; i < XB; ++i) xf[i] = *(const uint4*)(patch + swz((XB * wm + i + dy) * PW + l31 + dx, ch));
 #pragma unroll
         for (int j = 0; j < 4; ++j) wf[j] = *(const uint4*)(wb + swz(wn * 128 + j * 32 + l31, ch));
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < XB; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma32(wf[j], xf[i], acc[i][j]);
       }
@@ -192,10 +195,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(const pmi_ig
     for (int c = tid; c < 2 * BN; c += NT) stat[c] = 0.f;
     __syncthreads();
   }
-  int64_t mpix[2], rrow[2];
+  int64_t mpix[XB], rrow[XB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int y = y0 + 2 * wm + i, x = x0 + l31;
+  for (int i = 0; i < XB; ++i) {
+    const int y = y0 + XB * wm + i, x = x0 + l31;
     mpix[i] = ((int64_t)img * a.H + y) * a.W + x;
     rrow[i] = mpix[i] * a.ldr;
     if (a.R && a.res_up) rrow[i] = (((int64_t)img * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.ldr;
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv3x3_halo_kernel(const pmi_ig
 #pragma unroll
     for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < XB; ++i) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = n0 + wn * 128 + j * 32 + 4 * lhi + 8 * g;
@@ -257,6 +260,9 @@ int launch_p(const pmi_igemm_args& a, hipStream_t s, int cfg) {
   } else if (cfg == 1) {   // 16x32 px x 128 ch, 8 waves
     const int tiles = nimg * (a.H / 16) * (a.W / 32) * ((a.N + 127) / 128);
     hipLaunchKernelGGL((conv3x3_halo_kernel<T, 8, 1, PRO, PRO == 0>), dim3(tiles), dim3(512), 0, s, a);
+  } else if (cfg == 3) {   // 8x32 px x 256 ch, 4 waves of 128 px x 128 ch, one wave per SIMD (512 registers each)
+    const int tiles = nimg * (a.H / 8) * (a.W / 32) * ((a.N + 255) / 256);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, 2, 2, PRO, true, 4>), dim3(tiles), dim3(256), 0, s, a);
   } else {                 // 8x32 px x 128 ch, 4 waves, two workgroups per CU overlap each other's staging / epilogue
     const int tiles = nimg * (a.H / 8) * (a.W / 32) * ((a.N + 127) / 128);
     hipLaunchKernelGGL((conv3x3_halo_kernel<T, 4, 1, PRO, false>), dim3(tiles), dim3(256), 0, s, a);
@@ -294,6 +300,7 @@ extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
   if (g_force_cfg == 0 && ok0) return 0;
   if (g_force_cfg == 1 && ok1) return 1;
   if (g_force_cfg == 2) return 2;
+  if (g_force_cfg == 3 && (a->N % 256) == 0) return 3;
   // One 8-wave workgroup per CU: a grid well below 256 workgroups leaves CUs idle; such layers (<= 32x32 feature maps
   // at batch 8) go to the generic kernel, whose 128x128 tiles (and split-K) fill the chip.
   const int nimg = a->M / (a->H * a->W);

@@ -91,6 +91,20 @@ __global__ __launch_bounds__(256) void upsample_bilinear2_kernel(const u16* __re
   }
 }
 
+// nearest x2 (wikiart_256.py:117): 16-byte copies
+__global__ __launch_bounds__(256) void upsample_nearest2_kernel(const u16* __restrict__ x, u16* __restrict__ y, int N, int H, int W, int C) {
+  const int C8 = C >> 3, Ho = H * 2, Wo = W * 2;
+  const int64_t total = (int64_t)N * Ho * Wo * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int n = (int)(pix / ((int64_t)Ho * Wo));
+    const int rem = (int)(pix - (int64_t)n * Ho * Wo);
+    const int oy = rem / Wo, ox = rem - oy * Wo;
+    *(uint4*)(y + pix * C + c8 * 8) = *(const uint4*)(x + (((int64_t)n * H + (oy >> 1)) * W + (ox >> 1)) * C + c8 * 8);
+  }
+}
+
 template <typename T>
 __global__ void timestep_embedding_kernel(const float* __restrict__ t, u16* __restrict__ out, int N, int dim, float max_period) {
   const int half = dim / 2;
@@ -215,6 +229,12 @@ extern "C" int pmi_upsample_bilinear2(const void* x, void* y, int N, int H, int 
   if (!x || !y || N <= 0 || H <= 0 || W <= 0 || (C & 7)) return PMI_ERR_ARG;
   dim3 grid(grid_for((int64_t)N * H * W * 4 * (C / 8))), block(256);
   BY_DTYPE(upsample_bilinear2_kernel, (const u16*)x, (u16*)y, N, H, W, C);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_upsample_nearest2(const void* x, void* y, int N, int H, int W, int C, pmi_stream_t s) {
+  if (!x || !y || N <= 0 || H <= 0 || W <= 0 || (C & 7)) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(upsample_nearest2_kernel, dim3(grid_for((int64_t)N * H * W * 4 * (C / 8))), dim3(256), 0, ST, (const u16*)x, (u16*)y, N, H, W, C);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }

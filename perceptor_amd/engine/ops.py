@@ -210,6 +210,13 @@ def upsample_bilinear2(x: torch.Tensor, dt: int) -> torch.Tensor:
     return y
 
 
+def upsample_nearest2(x: torch.Tensor) -> torch.Tensor:
+    n, h, w, c = x.shape
+    y = _empty((n, h * 2, w * 2, c), x.dtype, x.device)
+    call("pmi_upsample_nearest2", ptr(x), ptr(y), n, h, w, c)
+    return y
+
+
 def attention(qkv: torch.Tensor, heads: int, order: int, dt: int) -> torch.Tensor:
     """Self-attention over tokens.  qkv: [N, T, 3C] 16-bit -> [N, T, C].
 

@@ -75,13 +75,15 @@ def _level(cs: List[int], i: int, attn_from: int, side: int, inner: int) -> list
     return prog
 
 
-def make_spec(name: str, shape, cs: List[int], top: int, side: int, inner: int, attn_from: int, cond: bool, feats: int = 1024):
+def make_spec(name: str, shape, cs: List[int], top: int, side: int, inner: int, attn_from: int, cond: bool, feats: int = 1024,
+              head_dim: int = 64, attn_norm: bool = True, up_mode: str = "bilinear", t_input: str = "t", skip_first: bool = False):
     prog = [Res(3 + 16, cs[0], cs[0])] + [Res(cs[0], cs[0], cs[0]) for _ in range(top - 1)]
     prog.append(Skip(_level(cs, 1, attn_from, side, inner)))
     prog.append(Res(2 * cs[0], cs[0], cs[0]))
     prog += [Res(cs[0], cs[0], cs[0]) for _ in range(top - 2)]
     prog.append(Res(cs[0], cs[0], 3, last=True))
-    return dict(name=name, shape=tuple(shape), cond=cond, feats=feats, net=prog)
+    return dict(name=name, shape=tuple(shape), cond=cond, feats=feats, net=prog, head_dim=head_dim, attn_norm=attn_norm,
+                up_mode=up_mode, t_input=t_input, skip_first=skip_first)
 
 
 def yfcc2_spec():   # yfcc_2.py:77-245
@@ -92,6 +94,17 @@ def yfcc2_spec():   # yfcc_2.py:77-245
 def cc12m1_spec():  # cc12m_1.py:112-291
     c = 128
     return make_spec("cc12m_1", (3, 256, 256), [c, c * 2, c * 2, c * 4, c * 4, c * 8, c * 8], 4, 4, 8, 4, True)
+
+
+def yfcc1_spec():   # yfcc_1.py:78-336
+    c = 128
+    return make_spec("yfcc_1", (3, 512, 512), [c, c, c * 2, c * 2, c * 4, c * 4, c * 8, c * 8], 4, 4, 8, 5, False)
+
+
+def wikiart_spec():  # wikiart_256.py:105-291: no norm in attention, 128-channel heads, nearest upsampling, Fourier features of log-SNR(t)
+    c = 128
+    return make_spec("wikiart", (3, 256, 256), [c // 2, c, c * 2, c * 2, c * 4, c * 4, c * 8], 4, 4, 8, 4, False,
+                     head_dim=128, attn_norm=False, up_mode="nearest", t_input="log_snr", skip_first=True)
 
 
 def _walk(prog, prefix, fn):
@@ -127,7 +140,8 @@ def state_dict_shapes(spec) -> Dict[str, Tuple[int, ...]]:
             if l.cin != l.cout:
                 S[p + ".skip.weight"] = (l.cout, l.cin, 1, 1)
         elif isinstance(l, Attn):
-            S[p + ".norm.weight"] = (l.c,); S[p + ".norm.bias"] = (l.c,)
+            if spec.get("attn_norm", True):
+                S[p + ".norm.weight"] = (l.c,); S[p + ".norm.bias"] = (l.c,)
             S[p + ".qkv_proj.weight"] = (3 * l.c, l.c, 1, 1); S[p + ".qkv_proj.bias"] = (3 * l.c,)
             S[p + ".out_proj.weight"] = (l.c, l.c, 1, 1); S[p + ".out_proj.bias"] = (l.c,)
 
@@ -161,7 +175,8 @@ class VDiffEngine:
                     if not l.last:
                         l.mod2 = off[0]; mods.append(sd[p + ".main.6.layer.weight"].float()); off[0] += 2 * l.cout
             elif isinstance(l, Attn):
-                self.w[p + ".gn"] = (f32(p + ".norm.weight"), f32(p + ".norm.bias"))
+                if spec.get("attn_norm", True):
+                    self.w[p + ".gn"] = (f32(p + ".norm.weight"), f32(p + ".norm.bias"))
                 self.w[p + ".qkv"] = PackedLinear(sd[p + ".qkv_proj.weight"], sd[p + ".qkv_proj.bias"], dt, dev)
                 self.w[p + ".out"] = PackedLinear(sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"], dt, dev)
 
@@ -198,10 +213,12 @@ class VDiffEngine:
     def _attn(self, l: Attn, p, x):
         dt, w = self.dt, self.w
         n, hh, ww, c = x.shape
-        g, b = w[p + ".gn"]
-        hn = ops.group_norm(x, g, b, 1, dt)
+        hn = x
+        if self.spec.get("attn_norm", True):
+            g, b = w[p + ".gn"]
+            hn = ops.group_norm(x, g, b, 1, dt)
         qkv = ops.igemm(hn.view(n * hh * ww, c), w[p + ".qkv"])
-        a = ops.attention(qkv.view(n, hh * ww, 3 * c), c // 64, 1, dt)
+        a = ops.attention(qkv.view(n, hh * ww, 3 * c), c // self.spec.get("head_dim", 64), 1, dt)
         return ops.igemm(a.view(n * hh * ww, c), w[p + ".out"], residual=x.view(n * hh * ww, c)).view(n, hh, ww, c)
 
     def _run(self, prog, prefix, x, mod):
@@ -215,10 +232,12 @@ class VDiffEngine:
             elif isinstance(l, Down):
                 x = ops.avgpool2(x, self.dt)
             elif isinstance(l, Up):
-                x = ops.upsample_bilinear2(x, self.dt)
+                x = ops.upsample_nearest2(x) if self.spec.get("up_mode") == "nearest" else ops.upsample_bilinear2(x, self.dt)
             elif isinstance(l, Skip):
-                # torch.cat([main(x), x], dim=1): main first, then the skip path (yfcc_2.py:31-38)
-                x, x1 = self._run(l.main, p + ".main", x, mod), x
+                # torch.cat([main(x), x], dim=1): main first, then the skip path (yfcc_2.py:31-38);
+                # wikiart concatenates the other way round (wikiart_256.py:86-87)
+                inner = self._run(l.main, p + ".main", x, mod)
+                x, x1 = (x, inner) if self.spec.get("skip_first") else (inner, x)
         assert x1 is None
         return x
 
@@ -257,7 +276,10 @@ class VDiffEngine:
                 raise ValueError("this model is CLIP-conditioned: clip_embed is required")
             mod = self._mapping(t, clip_embed)
         planes = torch.empty((n, 16), dtype=torch.float32, device=dev)
-        call("pmi_fourier_features", ptr(t), ptr(self.tw), ptr(planes), n, 8)
+        tf = t
+        if self.spec.get("t_input") == "log_snr":       # wikiart_256.py:288-292: features of log(alpha^2 / sigma^2), [N] scalars
+            tf = torch.log(torch.cos(t * (torch.pi / 2)) ** 2 / torch.sin(t * (torch.pi / 2)) ** 2).contiguous()
+        call("pmi_fourier_features", ptr(tf), ptr(self.tw), ptr(planes), n, 8)
         x = torch.empty((n, hh, ww, 24), dtype=_hip.TORCH_DTYPE[dt], device=dev)
         call("pmi_prep_input", ptr(images), ptr(planes), 16, ptr(x), n, hh, ww, 24, dt)
         y = self._run(self.spec["net"], "net", x, mod)

@@ -12,15 +12,17 @@ from ..guided_diffusion.guided_diffusion import WeightStore
 from . import diffusion_space, utils
 from .predictions import Predictions
 
-_SPECS = {"yfcc_2": vdiff.yfcc2_spec, "cc12m_1": vdiff.cc12m1_spec, "cc12m_1_cfg": vdiff.cc12m1_spec}
-_LATER = ("yfcc_1", "wikiart")   # same family, not built yet
+_SPECS = {"yfcc_2": vdiff.yfcc2_spec, "yfcc_1": vdiff.yfcc1_spec, "cc12m_1": vdiff.cc12m1_spec, "cc12m_1_cfg": vdiff.cc12m1_spec,
+          "wikiart": vdiff.wikiart_spec}
+_LATER = ()
 
 
 class VelocityDiffusion(torch.nn.Module):
-    def __init__(self, name="yfcc_2", *, weights="synthetic", checkpoint: Optional[str] = None, dtype="bf16", seed=0, spec=None):
+    def __init__(self, name="yfcc_2", *, weights="synthetic", checkpoint: Optional[str] = None, dtype="bf16", seed=0, spec=None,
+                 weight_gain: float = 1.0):
         """
         Args:
-            name: The name of the model. Available models are: yfcc_2, cc12m_1_cfg (conditioned)
+            name: The name of the model. Available models are: yfcc_2, yfcc_1, cc12m_1_cfg (conditioned), wikiart
         """
         super().__init__()
         self.name = name
@@ -37,7 +39,7 @@ class VelocityDiffusion(torch.nn.Module):
         if checkpoint is not None:
             sd = {k: v.float() for k, v in torch.load(checkpoint, map_location="cpu", weights_only=True).items()}
         elif weights == "synthetic":
-            sd = synth_state_dict(shapes, seed)
+            sd = synth_state_dict(shapes, seed, gain=weight_gain)
         else:
             raise ValueError("weights must be 'synthetic' or a checkpoint path must be given (no network access)")
         if set(sd) != set(shapes):

@@ -35,7 +35,7 @@ def _rng(name: str, seed: int) -> np.random.Generator:
     return np.random.Generator(np.random.Philox(key=key))
 
 
-def synth_tensor(name: str, shape: Sequence[int], seed: int = 0) -> torch.Tensor:
+def synth_tensor(name: str, shape: Sequence[int], seed: int = 0, gain: float = 1.0) -> torch.Tensor:
     shape = tuple(int(s) for s in shape)
     g = _rng(name, seed)
     leaf = name.rsplit(".", 1)[-1]
@@ -47,7 +47,7 @@ def synth_tensor(name: str, shape: Sequence[int], seed: int = 0) -> torch.Tensor
         w = z * float(shape[0]) ** -0.5
     elif len(shape) >= 2:
         fan_in = int(np.prod(shape[1:]))
-        w = z * float(fan_in) ** -0.5
+        w = z * (gain * float(fan_in) ** -0.5)   # gain < 1 keeps deep norm-free nets (wikiart) inside the fp16 range
     elif leaf in ("weight",):  # norm gains
         w = 1.0 + 0.1 * z
     else:  # biases and other vectors
@@ -57,21 +57,21 @@ def synth_tensor(name: str, shape: Sequence[int], seed: int = 0) -> torch.Tensor
     return torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32))
 
 
-def synth_state_dict(shapes: Mapping[str, Sequence[int]], seed: int = 0, workers: int = 8) -> Dict[str, torch.Tensor]:
+def synth_state_dict(shapes: Mapping[str, Sequence[int]], seed: int = 0, workers: int = 8, gain: float = 1.0) -> Dict[str, torch.Tensor]:
     """Each tensor has its own name-keyed stream, so generation order / threading cannot change values."""
     from concurrent.futures import ThreadPoolExecutor
     keys = list(shapes)
     with ThreadPoolExecutor(max_workers=workers) as ex:
-        vals = list(ex.map(lambda k: synth_tensor(k, shapes[k], seed), keys))
+        vals = list(ex.map(lambda k: synth_tensor(k, shapes[k], seed, gain), keys))
     return dict(zip(keys, vals))
 
 
-def synth_like(state_dict: Mapping[str, torch.Tensor], seed: int = 0) -> Dict[str, torch.Tensor]:
+def synth_like(state_dict: Mapping[str, torch.Tensor], seed: int = 0, gain: float = 1.0) -> Dict[str, torch.Tensor]:
     """Synthetic replacement for every floating-point entry of ``state_dict``."""
     out = {}
     for k, v in state_dict.items():
         if torch.is_floating_point(v):
-            out[k] = synth_tensor(k, v.shape, seed).to(v.dtype)
+            out[k] = synth_tensor(k, v.shape, seed, gain).to(v.dtype)
         else:
             out[k] = v.clone()
     return out

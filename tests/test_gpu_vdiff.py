@@ -57,3 +57,14 @@ def test_cc12m1_full_64_vs_reference_golden(dtype):
     pred = m(((g["x"] + 1) / 2).cuda(), g["t"].cuda(), conditioning=g["clip_embed"][None].cuda())
     nxt = pred.step(torch.tensor([0.6]))
     assert torch.isfinite(nxt).all() and nxt.shape == (1, 3, 64, 64)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("name,res,gain", [("yfcc_1", 128, 1.0), ("wikiart", 64, 0.6)])
+def test_yfcc1_wikiart_full_vs_reference_golden(name, res, gain, dtype):
+    """yfcc_1 (481 M) and wikiart (no-norm attention with 128-channel heads, nearest upsampling, log-SNR features)."""
+    from perceptor_amd import models
+    g = golden(f"vdiff_{name}_{res}")
+    m = models.VelocityDiffusion(name, dtype=dtype, weight_gain=gain).to("cuda")
+    v = m.velocities(((g["x"] + 1) / 2).cuda(), g["t"].cuda())
+    _compare(v[:, :, ::2, ::2], g["y_sub"], dtype, f"{name}@{res} vs reference golden")

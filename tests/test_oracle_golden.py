@@ -131,3 +131,12 @@ def test_vdiff_cc12m1_full_64():
     sd = synth_state_dict(vdiff.state_dict_shapes(spec), 0)
     y = vdiff.vdiff_forward(sd, spec, g["x"], g["t"], g["clip_embed"])
     _close(y[:, :, ::2, ::2], g["y_sub"], 1e-5)
+
+
+@pytest.mark.parametrize("name,res,spec_fn,gain", [("yfcc_1", 128, vdiff.yfcc1_spec, 1.0), ("wikiart", 64, vdiff.wikiart_spec, 0.6)])
+def test_vdiff_yfcc1_wikiart(name, res, spec_fn, gain):
+    g = golden(f"vdiff_{name}_{res}")
+    spec = spec_fn()
+    sd = synth_state_dict(vdiff.state_dict_shapes(spec), 0, gain=gain)
+    y = vdiff.vdiff_forward(sd, spec, g["x"], g["t"])
+    _close(y[:, :, ::2, ::2], g["y_sub"], 1e-5)
