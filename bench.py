@@ -28,13 +28,16 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0}   # dense MFMA peak, MI355X_MICROARCH.md (never the 2:1-sparse figure)
 
 # forward GFLOP / sample (torch flop counter on the reference modules)
-UNET_GFLOP = {"standard": {512: 3964.7, 256: 989.0}, "pixelart": {256: 497.5}}
+UNET_GFLOP = {"standard": {512: 3964.7, 256: 989.0}, "pixelart": {256: 497.5, 64: 497.5 / 16},
+              "yfcc_2": {512: 2314.3, 256: 578.4}, "yfcc_1": {512: 2058.1}, "cc12m_1_cfg": {256: 831.8}}
 CLIP_FWD_GFLOP = {"ViT-B-32": 8.82, "ViT-B-16": 35.13, "ViT-L-14": 162.03, "ViT-H-14": 334.59}
 
 CONFIGS = {
     # name: (model, resolution, batch per GPU, clip arch)
     "c5": ("standard", 512, 8, "ViT-L-14"),
+    "c1": ("cc12m_1_cfg", 256, 1, None),            # configs[0]: the reference's CPU-runnable case, here on the GPU
     "c2": ("standard", 256, 4, None),
+    "c3": ("yfcc_2", 512, 8, "ViT-B-32"),
     "c5-noclip": ("standard", 512, 8, None),
     "smoke": ("pixelart", 64, 2, None),
 }
@@ -50,6 +53,22 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-events", action="store_true")
     return p.parse_args()
+
+
+def cpu_baseline_v(model_name, res):
+    """v-diffusion nets: oracle forward at batch 1, 64x64 (cc12m_1) or 128x128 (yfcc), scaled by pixels x batch."""
+    from oracle import vdiff as ov
+    from perceptor_amd.utils.synth import seeded_noise, synth_state_dict
+    spec = {"yfcc_2": ov.yfcc2_spec, "yfcc_1": ov.yfcc1_spec, "cc12m_1_cfg": ov.cc12m1_spec}[model_name]()
+    sd = synth_state_dict(ov.state_dict_shapes(spec), 0)
+    sres = 128 if res >= 512 else 64
+    x = seeded_noise((1, 3, sres, sres), 1234)
+    t = torch.tensor([0.5])
+    ce = seeded_noise((1, 512), 11) if spec["cond"] else None
+    ov.vdiff_forward(sd, spec, x, t, ce)
+    t0 = time.time()
+    ov.vdiff_forward(sd, spec, x, t, ce)
+    return time.time() - t0, sres, torch.get_num_threads()
 
 
 def cpu_baseline(model_name, res, clip_arch, seed=0):
@@ -93,7 +112,9 @@ def main():
     from perceptor_amd.utils.synth import seeded_noise
 
     model_name, res, nb, clip_arch = CONFIGS[a.config]
-    model = models.GuidedDiffusion(model_name, dtype=a.dtype).to(dev)
+    is_v = model_name not in ("standard", "pixelart")
+    model = (models.VelocityDiffusion(model_name, dtype=a.dtype) if is_v else models.GuidedDiffusion(model_name, dtype=a.dtype)).to(dev)
+    cond = seeded_noise((1, 1, 512), 11).to(dev) if model_name.startswith("cc12m") else None
     clip_loss = None
     if clip_arch is not None:
         from perceptor_amd import losses
@@ -104,11 +125,11 @@ def main():
     noise = seeded_noise((nb * world, 3, res, res), 1234)[rank * nb:(rank + 1) * nb]
     images = (noise * 0.5 + 0.5).to(dev)
     n_sched = max(a.steps + a.warmup + 1, 50)
-    sched = model.schedule_indices(n_steps=n_sched, rho=7.0)
+    sched = model.schedule_ts(n_steps=n_sched).to(dev) if is_v else model.schedule_indices(n_steps=n_sched, rho=7.0)
 
     def one_step(images, i):
         fi, ti = sched[i % len(sched)]
-        pred = model.predictions(images, fi)
+        pred = model.predictions(images, fi, cond) if is_v else model.predictions(images, fi)
         if clip_loss is not None:
             _, grad = clip_loss.loss_and_grad(pred.denoised_images, n_total=nb * world)
             pred = pred.guided(grad, guidance_scale=0.5, clamp_value=1e-6)
@@ -161,13 +182,13 @@ def main():
                               "share_of_step": round(tot_ms / a.steps / step_ms_dev, 3)}
         out = {
             "metric": "denoising steps/sec (UNet+CLIP-grad) at 512x512 batch 8" if a.config == "c5" else f"denoising steps/sec ({a.config})",
-            "value": round(a.steps * world / elapsed, 4) if False else round(a.steps / elapsed * world, 4),
+            "value": round(a.steps / elapsed * world, 4),
             "unit": "steps/s (batch-8 steps summed over GPUs)",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"GuidedDiffusion '{model_name}' UNet {res}x{res}, batch {nb}/GPU"
+            "config": {"workload": f"{'VelocityDiffusion' if is_v else 'GuidedDiffusion'} '{model_name}' UNet {res}x{res}, batch {nb}/GPU"
                                    + (f" + OpenCLIP {clip_arch} guidance (fwd+bwd to image)" if clip_arch else " (no CLIP)")
                                    + ", DDIM eta=0, synthetic weights", "name": a.config,
                        "global_batch": nb * world, "parallelism": f"replica-sharded chains x{world}"},
@@ -175,7 +196,7 @@ def main():
             "roofline": roof,
         }
         if not a.no_cpu_baseline and world == 1:
-            t_unet, sres, cores = cpu_baseline(model_name, res, clip_arch)
+            t_unet, sres, cores = cpu_baseline_v(model_name, res) if is_v else cpu_baseline(model_name, res, clip_arch)
             scale = (res / sres) ** 2 * nb
             sec_step = t_unet * scale * (gflop_sample / UNET_GFLOP[model_name][res])
             out["cpu_baseline"] = {"value": round(1.0 / sec_step, 6), "unit": "steps/s (batch-8 steps)", "cores": cores, "kind": "port",

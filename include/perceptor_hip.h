@@ -105,6 +105,14 @@ int pmi_qkv_split(const void* qkv, void* q, void* k, void* vt, int N, int T, int
 int pmi_attn_d64(const void* q, const void* k, const void* vt, void* out, int N, int T, int heads, float scale,
                  int dtype, pmi_stream_t s);
 
+/* ViT attention with input-gradient (head dim 64, any T; nn.MultiheadAttention in ruclip/model.py:40-52), flash style:
+ * fwd: qkv [N][T][3C] with channels (q|k|v, head, d) -> out [N][T][C]; saves ws16 = 6 x [N*heads][Tp][64] 16-bit
+ *      (Q,K,V and their transposes, Tp = T rounded up to 32) and lse [N*heads][Tp] fp32 for the backward.
+ * bwd: dout [N][T][C] -> dqkv [N][T][3C]; needs o (= fwd out), ws16b = 2 x [N*heads][Tp][64] 16-bit and delta [N*heads][Tp] fp32 scratch. */
+int pmi_vit_attn_fwd(const void* qkv, void* ws16, float* lse, void* out, int N, int T, int heads, float scale, int dtype, pmi_stream_t s);
+int pmi_vit_attn_bwd(const void* ws16, const float* lse, const void* o, const void* dout, void* ws16b, float* delta, void* dqkv,
+                     int N, int T, int heads, float scale, int dtype, pmi_stream_t s);
+
 /* ---- layout / elementwise on the UNet path -----------------------------------------
  * prep: images NCHW fp32 in [0,1] -> x = 2*img-1 (diffusion_space.py:1-2) as NHWC 16-bit with
  *       Cpad channels; channels [3, 3+nplanes) are per-sample constants planes[n][j]

@@ -58,6 +58,8 @@ _PROTOS = {
     "pmi_gn_apply": ([_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],),
     "pmi_qkv_split": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],),
     "pmi_attn_d64": ([_P, _P, _P, _P, _I, _I, _I, _F, _I, _P],),
+    "pmi_vit_attn_fwd": ([_P, _P, _P, _P, _I, _I, _I, _F, _I, _P],),
+    "pmi_vit_attn_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P],),
     "pmi_prep_input": ([_P, _P, _I, _P, _I, _I, _I, _I, _I, _P],),
     "pmi_finish_output": ([_P, _I, _P, _I, _I, _I, _I, _P],),
     "pmi_avgpool2": ([_P, _P, _I, _I, _I, _I, _I, _P],),

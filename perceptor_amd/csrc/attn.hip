@@ -151,3 +151,317 @@ extern "C" int pmi_attn_d64(const void* q, const void* k, const void* vt, void* 
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }
+
+// =====================================================================================================================
+// ViT attention with backward (head dim 64, any T): forward saves O and the log-sum-exp; backward is two kernels that
+// each recompute the 32x32 probability blocks on MFMA (no T x T matrix in HBM, no transposes, no atomics):
+//   dq kernel   : one wave per 32-query tile, loops over key tiles    -> dQ
+//   dkdv kernel : one wave per 32-key tile,   loops over query tiles  -> dK, dV
+// Layouts (all 16-bit, Tp = T rounded up to 32, zero filled): Q,K,V,dO [B*H][Tp][64]; Qt,Kt,Vt,dOt [B*H][64][Tp];
+// lse, delta fp32 [B*H][Tp]  (delta[t] = sum_d dO[t][d] * O[t][d]).
+// Replaces nn.MultiheadAttention forward + autograd in the CLIP tower (ruclip/model.py:40-52).
+// =====================================================================================================================
+namespace {
+
+// qkv [N][T][3C] with channels (which, head, d) -> Q,K,V [bh][Tp][64] and Qt,Kt,Vt [bh][64][Tp]
+template <typename T_>
+__global__ __launch_bounds__(256) void vit_qkv_split_kernel(const u16* __restrict__ qkv, u16* __restrict__ q, u16* __restrict__ k,
+                                                            u16* __restrict__ v, u16* __restrict__ qt, u16* __restrict__ kt,
+                                                            u16* __restrict__ vt, int T, int Tp, int heads) {
+  __shared__ u16 s[3][32][72];
+  const int tid = threadIdx.x, t0 = blockIdx.x * 32, bh = blockIdx.y;
+  const int n = bh / heads, h = bh - n * heads, C = heads * 64;
+  const int row = tid >> 3, ch = tid & 7, t = t0 + row;
+  u16* dst[3] = {q, k, v};
+  u16* dstt[3] = {qt, kt, vt};
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (t < T) val = *(const uint4*)(qkv + ((int64_t)n * T + t) * 3 * C + w * C + h * 64 + ch * 8);
+    *(uint4*)(dst[w] + ((int64_t)bh * Tp + t) * 64 + ch * 8) = val;
+    *(uint4*)(&s[w][row][ch * 8]) = val;
+  }
+  __syncthreads();
+  const int d = tid >> 2, tc = tid & 3;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    u16 e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = s[w][tc * 8 + j][d];
+    *(uint4*)(dstt[w] + ((int64_t)bh * 64 + d) * Tp + t0 + tc * 8) =
+        make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+  }
+}
+
+// dO [N][T][C] (head, d) -> dO [bh][Tp][64], dOt [bh][64][Tp], delta[bh][Tp] = sum_d dO*O   (O in [N][T][C])
+template <typename T_>
+__global__ __launch_bounds__(256) void vit_do_prep_kernel(const u16* __restrict__ dout, const u16* __restrict__ o,
+                                                          u16* __restrict__ d_o, u16* __restrict__ d_ot, float* __restrict__ delta,
+                                                          int T, int Tp, int heads) {
+  __shared__ u16 s[32][72];
+  const int tid = threadIdx.x, t0 = blockIdx.x * 32, bh = blockIdx.y;
+  const int n = bh / heads, h = bh - n * heads, C = heads * 64;
+  const int row = tid >> 3, ch = tid & 7, t = t0 + row;
+  uint4 val = make_uint4(0, 0, 0, 0), ov = val;
+  if (t < T) {
+    val = *(const uint4*)(dout + ((int64_t)n * T + t) * C + h * 64 + ch * 8);
+    ov = *(const uint4*)(o + ((int64_t)n * T + t) * C + h * 64 + ch * 8);
+  }
+  *(uint4*)(d_o + ((int64_t)bh * Tp + t) * 64 + ch * 8) = val;
+  *(uint4*)(&s[row][ch * 8]) = val;
+  float a[8], b[8], p = 0.f;
+  unpack8<T_>(val, a); unpack8<T_>(ov, b);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) p += a[e] * b[e];
+  p += __shfl_xor(p, 1); p += __shfl_xor(p, 2); p += __shfl_xor(p, 4);
+  if (ch == 0) delta[(int64_t)bh * Tp + t] = p;
+  __syncthreads();
+  const int d = tid >> 2, tc = tid & 3;
+  u16 e[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) e[j] = s[tc * 8 + j][d];
+  *(uint4*)(d_ot + ((int64_t)bh * 64 + d) * Tp + t0 + tc * 8) =
+      make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
+}
+
+// forward: as attn_d64_kernel, plus lse[bh][t] = m + log(l)
+template <typename T_>
+__global__ __launch_bounds__(64) void vit_attn_fwd_kernel(const u16* __restrict__ q, const u16* __restrict__ k, const u16* __restrict__ vt,
+                                                          u16* __restrict__ out, float* __restrict__ lse, int T, int Tp, int heads, float scale) {
+  const int lane = threadIdx.x, l31 = lane & 31, lhi = lane >> 5;
+  const int t0 = blockIdx.x * 32, bh = blockIdx.y;
+  const u16* qb = q + ((int64_t)bh * Tp + t0 + l31) * 64 + 8 * lhi;
+  const u16* kb = k + (int64_t)bh * Tp * 64 + 8 * lhi;
+  const u16* vb = vt + (int64_t)bh * 64 * Tp;
+  uint4 qf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const uint4*)(qb + kk * 16);
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -1e30f, l_run = 0.f;
+  for (int s0 = 0; s0 < Tp; s0 += 32) {
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) sacc = T_::mfma32(*(const uint4*)(kb + (int64_t)(s0 + l31) * 64 + kk * 16), qf[kk], sacc);
+    float mx = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int s = s0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const float v = s < T ? sacc[r] * scale : -1e30f;
+      sacc[r] = v; mx = fmaxf(mx, v);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx), alpha = __expf(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float p = __expf(sacc[r] - m_new); sacc[r] = p; rs += p; }
+    rs += __shfl_xor(rs, 32);
+    l_run = l_run * alpha + rs; m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      float pf[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = sacc[8 * ks + j];
+      const uint4 pfrag = pack8<T_>(pf);
+      const int sk = s0 + 16 * ks + 4 * lhi;
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const u16* vp = vb + (int64_t)(db * 32 + l31) * Tp + sk;
+        const uint2 lo = *(const uint2*)vp, hi = *(const uint2*)(vp + 8);
+        const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        if (db == 0) o0 = T_::mfma32(vf, pfrag, o0); else o1 = T_::mfma32(vf, pfrag, o1);
+      }
+    }
+  }
+  const int t = t0 + l31;
+  if (lhi == 0) lse[(int64_t)bh * Tp + t] = t < T ? m_run + __logf(l_run) : 0.f;
+  if (t < T) {
+    const float inv = 1.f / l_run;
+    const int n = bh / heads, h = bh - n * heads;
+    u16* ob = out + ((int64_t)n * T + t) * (heads * 64) + h * 64 + 4 * lhi;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *(uint2*)(ob + 8 * g) = pack4<T_>(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+      *(uint2*)(ob + 32 + 8 * g) = pack4<T_>(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+    }
+  }
+}
+
+// dQ: wave per 32-query tile.  S^T = K.Q^T and dP^T = V.dO^T put the query on the lane, so lse/delta are lane-local;
+// dS^T (accumulator) is the B operand of dQ^T += K^T . dS^T without any movement.
+template <typename T_>
+__global__ __launch_bounds__(64) void vit_attn_dq_kernel(const u16* __restrict__ q, const u16* __restrict__ k, const u16* __restrict__ v,
+                                                         const u16* __restrict__ kt, const u16* __restrict__ d_o,
+                                                         const float* __restrict__ lse, const float* __restrict__ delta,
+                                                         u16* __restrict__ dqkv, int T, int Tp, int heads, float scale) {
+  const int lane = threadIdx.x, l31 = lane & 31, lhi = lane >> 5;
+  const int t0 = blockIdx.x * 32, bh = blockIdx.y;
+  const int64_t rb = (int64_t)bh * Tp;
+  uint4 qf[4], dof[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    qf[kk] = *(const uint4*)(q + (rb + t0 + l31) * 64 + kk * 16 + 8 * lhi);
+    dof[kk] = *(const uint4*)(d_o + (rb + t0 + l31) * 64 + kk * 16 + 8 * lhi);
+  }
+  const float my_lse = lse[rb + t0 + l31], my_delta = delta[rb + t0 + l31];
+  f32x16 g0, g1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
+  for (int s0 = 0; s0 < Tp; s0 += 32) {
+    f32x16 sacc, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      sacc = T_::mfma32(*(const uint4*)(k + (rb + s0 + l31) * 64 + kk * 16 + 8 * lhi), qf[kk], sacc);
+      dp = T_::mfma32(*(const uint4*)(v + (rb + s0 + l31) * 64 + kk * 16 + 8 * lhi), dof[kk], dp);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int s = s0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const float p = s < T ? __expf(sacc[r] * scale - my_lse) : 0.f;
+      sacc[r] = p * (dp[r] - my_delta) * scale;                 // dS^T[s][t]
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = sacc[8 * ks + j];
+      const uint4 dsf = pack8<T_>(f);
+      const int sk = s0 + 16 * ks + 4 * lhi;
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const u16* kp = kt + ((int64_t)bh * 64 + db * 32 + l31) * Tp + sk;
+        const uint2 lo = *(const uint2*)kp, hi = *(const uint2*)(kp + 8);
+        const uint4 kf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        if (db == 0) g0 = T_::mfma32(kf, dsf, g0); else g1 = T_::mfma32(kf, dsf, g1);
+      }
+    }
+  }
+  const int t = t0 + l31;
+  if (t < T) {
+    const int n = bh / heads, h = bh - n * heads, C = heads * 64;
+    u16* ob = dqkv + ((int64_t)n * T + t) * 3 * C + h * 64 + 4 * lhi;        // dQ slot
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *(uint2*)(ob + 8 * g) = pack4<T_>(g0[4 * g], g0[4 * g + 1], g0[4 * g + 2], g0[4 * g + 3]);
+      *(uint2*)(ob + 32 + 8 * g) = pack4<T_>(g1[4 * g], g1[4 * g + 1], g1[4 * g + 2], g1[4 * g + 3]);
+    }
+  }
+}
+
+// dK, dV: wave per 32-key tile.  S = Q.K^T and dP = dO.V^T put the key on the lane and the query on the accumulator rows,
+// so P and dS are the B operands of dV^T += dO^T . P and dK^T += Q^T . dS.
+template <typename T_>
+__global__ __launch_bounds__(64) void vit_attn_dkdv_kernel(const u16* __restrict__ q, const u16* __restrict__ k, const u16* __restrict__ v,
+                                                           const u16* __restrict__ qt, const u16* __restrict__ d_o, const u16* __restrict__ d_ot,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           u16* __restrict__ dqkv, int T, int Tp, int heads, float scale) {
+  const int lane = threadIdx.x, l31 = lane & 31, lhi = lane >> 5;
+  const int s0 = blockIdx.x * 32, bh = blockIdx.y;
+  const int64_t rb = (int64_t)bh * Tp;
+  uint4 kf[4], vf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    kf[kk] = *(const uint4*)(k + (rb + s0 + l31) * 64 + kk * 16 + 8 * lhi);
+    vf[kk] = *(const uint4*)(v + (rb + s0 + l31) * 64 + kk * 16 + 8 * lhi);
+  }
+  const bool key_ok = s0 + l31 < T;
+  f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
+  for (int t0 = 0; t0 < Tp; t0 += 32) {
+    f32x16 sacc, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      sacc = T_::mfma32(*(const uint4*)(q + (rb + t0 + l31) * 64 + kk * 16 + 8 * lhi), kf[kk], sacc);     // rows = queries, lane = key
+      dp = T_::mfma32(*(const uint4*)(d_o + (rb + t0 + l31) * 64 + kk * 16 + 8 * lhi), vf[kk], dp);
+    }
+    float pf[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const float p = (key_ok && t < T) ? __expf(sacc[r] * scale - lse[rb + t]) : 0.f;
+      pf[r] = p;
+      sacc[r] = p * (dp[r] - delta[rb + t]) * scale;            // dS[t][s]
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint4 pfrag = pack8<T_>(pf + 8 * ks);
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = sacc[8 * ks + j];
+      const uint4 dsf = pack8<T_>(f);
+      const int tk = t0 + 16 * ks + 4 * lhi;
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const u16* dp_ = d_ot + ((int64_t)bh * 64 + db * 32 + l31) * Tp + tk;
+        const u16* qp_ = qt + ((int64_t)bh * 64 + db * 32 + l31) * Tp + tk;
+        const uint2 a0 = *(const uint2*)dp_, a1 = *(const uint2*)(dp_ + 8);
+        const uint2 b0 = *(const uint2*)qp_, b1 = *(const uint2*)(qp_ + 8);
+        const uint4 dof = make_uint4(a0.x, a0.y, a1.x, a1.y), qf = make_uint4(b0.x, b0.y, b1.x, b1.y);
+        if (db == 0) { dv0 = T_::mfma32(dof, pfrag, dv0); dk0 = T_::mfma32(qf, dsf, dk0); }
+        else { dv1 = T_::mfma32(dof, pfrag, dv1); dk1 = T_::mfma32(qf, dsf, dk1); }
+      }
+    }
+  }
+  const int s = s0 + l31;
+  if (s < T) {
+    const int n = bh / heads, h = bh - n * heads, C = heads * 64;
+    u16* okp = dqkv + ((int64_t)n * T + s) * 3 * C + C + h * 64 + 4 * lhi;       // dK slot
+    u16* ovp = okp + C;                                                           // dV slot
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      *(uint2*)(okp + 8 * g) = pack4<T_>(dk0[4 * g], dk0[4 * g + 1], dk0[4 * g + 2], dk0[4 * g + 3]);
+      *(uint2*)(okp + 32 + 8 * g) = pack4<T_>(dk1[4 * g], dk1[4 * g + 1], dk1[4 * g + 2], dk1[4 * g + 3]);
+      *(uint2*)(ovp + 8 * g) = pack4<T_>(dv0[4 * g], dv0[4 * g + 1], dv0[4 * g + 2], dv0[4 * g + 3]);
+      *(uint2*)(ovp + 32 + 8 * g) = pack4<T_>(dv1[4 * g], dv1[4 * g + 1], dv1[4 * g + 2], dv1[4 * g + 3]);
+    }
+  }
+}
+
+}  // namespace
+
+#define VIT_BY_DTYPE(KERN, G, B, ...)                                                             \
+  do {                                                                                            \
+    if (dtype == PMI_DT_BF16) hipLaunchKernelGGL(KERN<BF16>, G, B, 0, (hipStream_t)s, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERN<F16>, G, B, 0, (hipStream_t)s, __VA_ARGS__);                     \
+  } while (0)
+
+extern "C" int pmi_vit_attn_fwd(const void* qkv, void* ws16, float* lse, void* out, int N, int T, int heads, float scale, int dtype,
+                                pmi_stream_t s) {
+  if (!qkv || !ws16 || !lse || !out || N <= 0 || T <= 0 || heads <= 0) return PMI_ERR_ARG;
+  const int Tp = (T + 31) / 32 * 32;
+  const int64_t blk = (int64_t)N * heads * Tp * 64;
+  u16* w = (u16*)ws16;   // Q, K, V, Qt, Kt, Vt
+  dim3 g(Tp / 32, N * heads);
+  VIT_BY_DTYPE(vit_qkv_split_kernel, g, dim3(256), (const u16*)qkv, w, w + blk, w + 2 * blk, w + 3 * blk, w + 4 * blk, w + 5 * blk, T, Tp, heads);
+  PMI_CHECK_LAUNCH();
+  VIT_BY_DTYPE(vit_attn_fwd_kernel, g, dim3(64), w, w + blk, w + 5 * blk, (u16*)out, lse, T, Tp, heads, scale);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+
+extern "C" int pmi_vit_attn_bwd(const void* ws16, const float* lse, const void* o, const void* dout, void* ws16b, float* delta,
+                                void* dqkv, int N, int T, int heads, float scale, int dtype, pmi_stream_t s) {
+  if (!ws16 || !lse || !o || !dout || !ws16b || !delta || !dqkv || N <= 0 || T <= 0 || heads <= 0) return PMI_ERR_ARG;
+  const int Tp = (T + 31) / 32 * 32;
+  const int64_t blk = (int64_t)N * heads * Tp * 64;
+  const u16* w = (const u16*)ws16;
+  u16* wb = (u16*)ws16b;   // dO, dOt
+  dim3 g(Tp / 32, N * heads);
+  VIT_BY_DTYPE(vit_do_prep_kernel, g, dim3(256), (const u16*)dout, (const u16*)o, wb, wb + blk, delta, T, Tp, heads);
+  PMI_CHECK_LAUNCH();
+  VIT_BY_DTYPE(vit_attn_dq_kernel, g, dim3(64), w, w + blk, w + 2 * blk, w + 4 * blk, wb, lse, delta, (u16*)dqkv, T, Tp, heads, scale);
+  PMI_CHECK_LAUNCH();
+  VIT_BY_DTYPE(vit_attn_dkdv_kernel, g, dim3(64), w, w + blk, w + 2 * blk, w + 3 * blk, wb, wb + blk, lse, delta, (u16*)dqkv, T, Tp, heads, scale);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}

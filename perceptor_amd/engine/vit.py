@@ -147,15 +147,24 @@ class VitEngine:
         for blk in self.blocks:
             h, _, mr1 = self._ln(x, width, blk["ln1"], m, width)
             qkv = ops.igemm(h, blk["qkv"].fwd)                                    # [m, 3*width], (q|k|v) x (head, d)
-            s = torch.empty((n * heads, t, tp), dtype=torch.float32, device=dev)
-            ops.bgemm(qkv, qkv, s, M=t, N=t, K=d, lda=3 * width, ldb=3 * width, ldd=tp, batch=n * heads, batch_inner=heads,
-                      sA=(t * 3 * width, d), sB=(t * 3 * width, d), sD=(heads * t * tp, t * tp), dt=dt, b_off=width)
-            p = torch.empty((n * heads, t, tp), dtype=tdt, device=dev)
-            call("pmi_softmax_fwd", ptr(s), ptr(p), n * heads * t, t, tp, tp, scale, dt)
-            vt = self._transpose(qkv, 2 * width, t, d, 3 * width, t * 3 * width, d, heads, n * heads)
             a = torch.empty((m, width), dtype=tdt, device=dev)
-            ops.bgemm(p, vt, a, M=t, N=d, K=tp, lda=tp, ldb=tp, ldd=width, batch=n * heads, batch_inner=heads,
-                      sA=(heads * t * tp, t * tp), sB=(heads * d * tp, d * tp), sD=(t * width, d), dt=dt)
+            fused = d == 64
+            if fused:   # flash-style kernels: no T x T matrix, no transposes (csrc/attn.hip)
+                tp32 = (t + 31) // 32 * 32
+                aws = torch.empty((6, n * heads, tp32, 64), dtype=tdt, device=dev)
+                lse = torch.empty((n * heads, tp32), dtype=torch.float32, device=dev)
+                call("pmi_vit_attn_fwd", ptr(qkv), ptr(aws), ptr(lse), ptr(a), n, t, heads, scale, dt)
+                p = None
+            else:
+                s = torch.empty((n * heads, t, tp), dtype=torch.float32, device=dev)
+                ops.bgemm(qkv, qkv, s, M=t, N=t, K=d, lda=3 * width, ldb=3 * width, ldd=tp, batch=n * heads, batch_inner=heads,
+                          sA=(t * 3 * width, d), sB=(t * 3 * width, d), sD=(heads * t * tp, t * tp), dt=dt, b_off=width)
+                p = torch.empty((n * heads, t, tp), dtype=tdt, device=dev)
+                call("pmi_softmax_fwd", ptr(s), ptr(p), n * heads * t, t, tp, tp, scale, dt)
+                vt = self._transpose(qkv, 2 * width, t, d, 3 * width, t * 3 * width, d, heads, n * heads)
+                ops.bgemm(p, vt, a, M=t, N=d, K=tp, lda=tp, ldb=tp, ldd=width, batch=n * heads, batch_inner=heads,
+                          sA=(heads * t * tp, t * tp), sB=(heads * d * tp, d * tp), sD=(t * width, d), dt=dt)
+                aws = lse = None
             x_mid = ops.igemm(a, blk["out"].fwd, residual=x, out_f32=True)
             h2, _, mr2 = self._ln(x_mid, width, blk["ln2"], m, width)
             hpre = ops.igemm(h2, blk["fc"].fwd)
@@ -163,7 +172,8 @@ class VitEngine:
             call("pmi_act_fwd", ptr(hpre), ptr(hact), hpre.numel(), self.act, dt)
             x_out = ops.igemm(hact, blk["pr"].fwd, residual=x_mid, out_f32=True)
             if save:
-                sv["layers"].append(dict(x_in=x, mr1=mr1, qkv=qkv, p=p, x_mid=x_mid, mr2=mr2, hpre=hpre))
+                sv["layers"].append(dict(x_in=x, mr1=mr1, qkv=qkv if not fused else None, p=p, aws=aws, lse=lse, a=a if fused else None,
+                                         x_mid=x_mid, mr2=mr2, hpre=hpre))
             x = x_out
         y16, _, mr_post = self._ln(x, t * width, self.ln_post, n, width)         # cls token rows only
         emb = ops.igemm(y16, self.proj.fwd, out_f32=True)
@@ -203,25 +213,32 @@ class VitEngine:
             gm32, gm16 = self._ln_bwd(dln2, width, L["x_mid"], blk["ln2"], L["mr2"], g32, m, width)
             # ---- attention branch
             da = ops.igemm(gm16, blk["out"].bwd)                                    # dO, [m, w] (head, d)
-            qkv, p = L["qkv"], L["p"]
             w3 = 3 * width
-            dp = torch.empty((n * heads, t, tp), dtype=torch.float32, device=dev)
-            ops.bgemm(da, qkv, dp, M=t, N=t, K=d, lda=width, ldb=w3, ldd=tp, batch=n * heads, batch_inner=heads,
-                      sA=(t * width, d), sB=(t * w3, d), sD=(heads * t * tp, t * tp), dt=dt, b_off=2 * width)
-            ds = torch.empty((n * heads, t, tp), dtype=tdt, device=dev)
-            call("pmi_softmax_bwd", ptr(dp), ptr(p), ptr(ds), n * heads * t, t, tp, tp, scale, dt)
             dqkv = torch.empty((m, w3), dtype=tdt, device=dev)
-            pt = self._transpose(p, 0, t, t, tp, heads * t * tp, t * tp, heads, n * heads)          # [nh, t(s), tp(t)]
-            dot = self._transpose(da, 0, t, d, width, t * width, d, heads, n * heads)               # [nh, d, tp]
-            ops.bgemm(pt, dot, dqkv, M=t, N=d, K=tp, lda=tp, ldb=tp, ldd=w3, batch=n * heads, batch_inner=heads,
-                      sA=(heads * t * tp, t * tp), sB=(heads * d * tp, d * tp), sD=(t * w3, d), dt=dt, d_off=2 * width)   # dV
-            kt = self._transpose(qkv, width, t, d, w3, t * w3, d, heads, n * heads)
-            ops.bgemm(ds, kt, dqkv, M=t, N=d, K=tp, lda=tp, ldb=tp, ldd=w3, batch=n * heads, batch_inner=heads,
-                      sA=(heads * t * tp, t * tp), sB=(heads * d * tp, d * tp), sD=(t * w3, d), dt=dt)                    # dQ
-            dst = self._transpose(ds, 0, t, t, tp, heads * t * tp, t * tp, heads, n * heads)
-            qt = self._transpose(qkv, 0, t, d, w3, t * w3, d, heads, n * heads)
-            ops.bgemm(dst, qt, dqkv, M=t, N=d, K=tp, lda=tp, ldb=tp, ldd=w3, batch=n * heads, batch_inner=heads,
-                      sA=(heads * t * tp, t * tp), sB=(heads * d * tp, d * tp), sD=(t * w3, d), dt=dt, d_off=width)       # dK
+            if L["aws"] is not None:
+                tp32 = (t + 31) // 32 * 32
+                bws = torch.empty((2, n * heads, tp32, 64), dtype=tdt, device=dev)
+                delta = torch.empty((n * heads, tp32), dtype=torch.float32, device=dev)
+                call("pmi_vit_attn_bwd", ptr(L["aws"]), ptr(L["lse"]), ptr(L["a"]), ptr(da), ptr(bws), ptr(delta), ptr(dqkv),
+                     n, t, heads, scale, dt)
+            else:
+                qkv, p = L["qkv"], L["p"]
+                dp = torch.empty((n * heads, t, tp), dtype=torch.float32, device=dev)
+                ops.bgemm(da, qkv, dp, M=t, N=t, K=d, lda=width, ldb=w3, ldd=tp, batch=n * heads, batch_inner=heads,
+                          sA=(t * width, d), sB=(t * w3, d), sD=(heads * t * tp, t * tp), dt=dt, b_off=2 * width)
+                ds = torch.empty((n * heads, t, tp), dtype=tdt, device=dev)
+                call("pmi_softmax_bwd", ptr(dp), ptr(p), ptr(ds), n * heads * t, t, tp, tp, scale, dt)
+                pt = self._transpose(p, 0, t, t, tp, heads * t * tp, t * tp, heads, n * heads)          # [nh, t(s), tp(t)]
+                dot = self._transpose(da, 0, t, d, width, t * width, d, heads, n * heads)               # [nh, d, tp]
+                ops.bgemm(pt, dot, dqkv, M=t, N=d, K=tp, lda=tp, ldb=tp, ldd=w3, batch=n * heads, batch_inner=heads,
+                          sA=(heads * t * tp, t * tp), sB=(heads * d * tp, d * tp), sD=(t * w3, d), dt=dt, d_off=2 * width)   # dV
+                kt = self._transpose(qkv, width, t, d, w3, t * w3, d, heads, n * heads)
+                ops.bgemm(ds, kt, dqkv, M=t, N=d, K=tp, lda=tp, ldb=tp, ldd=w3, batch=n * heads, batch_inner=heads,
+                          sA=(heads * t * tp, t * tp), sB=(heads * d * tp, d * tp), sD=(t * w3, d), dt=dt)                    # dQ
+                dst = self._transpose(ds, 0, t, t, tp, heads * t * tp, t * tp, heads, n * heads)
+                qt = self._transpose(qkv, 0, t, d, w3, t * w3, d, heads, n * heads)
+                ops.bgemm(dst, qt, dqkv, M=t, N=d, K=tp, lda=tp, ldb=tp, ldd=w3, batch=n * heads, batch_inner=heads,
+                          sA=(heads * t * tp, t * tp), sB=(heads * d * tp, d * tp), sD=(t * w3, d), dt=dt, d_off=width)       # dK
             dln1 = ops.igemm(dqkv, blk["qkv"].bwd, out_f32=True)
             g32, g16 = self._ln_bwd(dln1, width, L["x_in"], blk["ln1"], L["mr1"], gm32, m, width)
         _, g0 = self._ln_bwd(g32, width, sv["x0"], self.ln_pre, sv["mr_pre"], None, m, width, want32=False)

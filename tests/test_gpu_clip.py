@@ -13,7 +13,8 @@ from conftest import golden
 
 pytestmark = pytest.mark.gpu
 
-TINY = {"tiny": (32, 8, 64, 2, 1, 32), "tiny-odd": (28, 14, 128, 2, 2, 48)}
+TINY = {"tiny": (32, 8, 64, 2, 1, 32), "tiny-odd": (28, 14, 128, 2, 2, 48),
+        "tiny-d32": (32, 8, 64, 2, 2, 32)}   # 32-channel heads: GEMM-based attention path (64-channel heads use the fused kernels)
 
 
 def _rel(a, b):
@@ -67,7 +68,7 @@ def test_vit_embedding_and_gradient_vs_reference_golden(tag):
     assert torch.allclose(f.norm(dim=1).float(), g["grad_mom"][:, 2], rtol=5e-2)
 
 
-@pytest.mark.parametrize("tag,gelu", [("tiny", False), ("tiny-odd", True)])
+@pytest.mark.parametrize("tag,gelu", [("tiny", False), ("tiny-odd", True), ("tiny-d32", True)])
 def test_loss_and_grad_vs_oracle_and_sharding(tag, gelu):
     from oracle import clip_vit
     from perceptor_amd import losses
