@@ -27,7 +27,10 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((ch
 // XB: image rows (32-pixel MFMA blocks) per wave.  XB = 2 with 8 waves (two waves per SIMD, 256 registers each) or XB = 4
 // with 4 waves (ONE wave per SIMD owning the whole 512-register file: 256 accumulators, 0.5 instead of 0.75 LDS fragment
 // reads per MFMA, nothing to arbitrate on the SIMD).
-template <typename T, int WM, int WN, int PRO, bool EARLY, int XB = 2>
+// INCR: two patch buffers; the next 64-channel chunk's patch is staged piecewise (one 16-byte piece per thread per tap,
+// GroupNorm prologue applied on the way) under taps 0..NPI-1 of the current chunk, so there is no bubble (two barriers + an
+// exposed load + ~500 VALU instructions per thread) at chunk boundaries and no 24-register patch prefetch.
+template <typename T, int WM, int WN, int PRO, bool EARLY, int XB = 2, bool INCR = false>
 __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_kernel(const pmi_igemm_args a) {
   constexpr int TH = WM * XB;                          // image rows per tile
   constexpr int NT = WM * WN * 64;                     // threads per workgroup
@@ -38,9 +41,9 @@ __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_ke
   constexpr int NWI = BN / RPI;                        // 16-byte weight chunks per thread per tap
   constexpr int PATCH_BYTES = PP * 128;
   constexpr int WBYTES = BN * 128;
-  __shared__ __attribute__((aligned(16))) char smem[PATCH_BYTES + 2 * WBYTES];
-  char* const patch = smem;
-  char* const wbuf = smem + PATCH_BYTES;
+  constexpr int NPB = INCR ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) char smem[NPB * PATCH_BYTES + 2 * WBYTES];
+  char* const wbuf = smem + NPB * PATCH_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -105,22 +108,47 @@ __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_ke
       *(float4*)gb = *(const float4*)pb; *(float4*)(gb + 4) = *(const float4*)(pb + 4);
     }
   };
-  auto store_patch = [&]() {
+  auto piece_off = [&](int i) -> int {                // source pixel of patch piece i (any i, computed, not looked up)
+    const int pp = (tid >> 3) + RPI * i;
+    if (pp >= PP) return -1;
+    const int py = pp / PW, px = pp - py * PW;
+    int sy = y0 - 1 + py, sx = x0 - 1 + px;
+    if (sy < 0 || sy >= Hv || sx < 0 || sx >= Wv) return -1;
+    if (a.up) { sy >>= 1; sx >>= 1; }
+    return (img * a.Hin + sy) * a.Win + sx;
+  };
+  auto store_piece = [&](char* pbuf, int i, uint4 v, int off) {
+    const int pp = (tid >> 3) + RPI * i;
+    if (pp < PP) {
+      if (PRO && off >= 0) {
+        float f[8];
+        unpack8<T>(v, f);
 #pragma unroll
-    for (int i = 0; i < NPI; ++i) {
-      const int pp = (tid >> 3) + RPI * i;
-      if (pp < PP) {
-        uint4 v = pr[i];
-        if (PRO && poff[i] >= 0) {
-          float f[8];
-          unpack8<T>(v, f);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] = act_apply(f[e] * ga[e] + gb[e], PRO - 1);
-          v = pack8<T>(f);
-        }
-        *(uint4*)(patch + swz(pp, sc)) = v;
+        for (int e = 0; e < 8; ++e) f[e] = act_apply(f[e] * ga[e] + gb[e], PRO - 1);
+        v = pack8<T>(f);
       }
+      *(uint4*)(pbuf + swz(pp, sc)) = v;
     }
+  };
+  auto store_patch = [&](char* pbuf) {
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) store_piece(pbuf, i, pr[i], poff[i]);
+  };
+  // INCR: piece i of chunk `chunk` (this thread's 16 bytes of patch pixel srow + RPI*i) and its prologue coefficients
+  auto load_piece = [&](int chunk, int off) -> uint4 {
+    const int ci = chunk * 64 + sc * 8;
+    const bool second = ci >= a.C0;
+    const u16* base = second ? A1 + (ci - a.C0) : A0 + ci;
+    const int ld = second ? a.lda1 : a.lda0;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (off >= 0) v = *(const uint4*)(base + (int64_t)off * ld);
+    if (PRO) {
+      const float* pa = a.pro_a + (int64_t)img * Cin + ci;
+      const float* pb = a.pro_b + (int64_t)img * Cin + ci;
+      *(float4*)ga = *(const float4*)pa; *(float4*)(ga + 4) = *(const float4*)(pa + 4);
+      *(float4*)gb = *(const float4*)pb; *(float4*)(gb + 4) = *(const float4*)(pb + 4);
+    }
+    return v;
   };
   auto load_w = [&](int chunk, int tap) {
     const int64_t koff = (int64_t)tap * Cin + chunk * 64;
@@ -148,21 +176,27 @@ __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_ke
   const int nchunks = Cin / 64;
   load_patch(0);
   load_w(0, 0);
-  store_patch();
+  store_patch(smem);
   store_w(0);
   __syncthreads();
   int cur = 0;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const char* const patch = smem + (INCR ? (chunk & 1) * PATCH_BYTES : 0);
+    char* const patch_next = smem + (INCR ? ((chunk + 1) & 1) * PATCH_BYTES : 0);
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
       const bool last_tap = tap == 8;
       const bool more_chunks = chunk + 1 < nchunks;
       const bool has_next = !last_tap || more_chunks;
       if (has_next) load_w(last_tap ? chunk + 1 : chunk, last_tap ? 0 : tap + 1);
+      uint4 piece = make_uint4(0, 0, 0, 0);
+      const bool stage = INCR && tap < NPI && more_chunks;
+      int poff_piece = -1;
+      if (stage) { poff_piece = piece_off(tap); piece = load_piece(chunk + 1, poff_piece); }
       // Without a prologue the next patch is prefetched into registers under the MFMAs of the last tap.  With the fused
       // GroupNorm prologue that would push the kernel over 256 VGPRs (spills), so the loads are issued after the MFMAs
       // instead (one exposed load latency per 64-channel chunk = per 288 MFMAs).
-      if (EARLY && last_tap && more_chunks) load_patch(chunk + 1);
+      if (!INCR && EARLY && last_tap && more_chunks) load_patch(chunk + 1);
       const int dy = tap / 3, dx = tap - dy * 3;        // patch row/col offset (tap - 1 + halo 1)
       const char* wb = wbuf + cur * WBYTES;
 #pragma unroll
@@ -179,10 +213,11 @@ __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_ke
           for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma32(wf[j], xf[i], acc[i][j]);
       }
       if (has_next) store_w(cur ^ 1);
-      if (last_tap && more_chunks) {
+      if (stage) store_piece(patch_next, tap, piece, poff_piece);
+      if (!INCR && last_tap && more_chunks) {
         if (!EARLY) load_patch(chunk + 1);
         __syncthreads();          // every wave is done reading the current patch
-        store_patch();
+        store_patch(smem);
       }
       __syncthreads();
       cur ^= 1;
@@ -251,12 +286,14 @@ __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_ke
   }
 }
 
+static int g_incr = 0;   // measured: no gain over the chunk-boundary staging (876 vs 943 TFLOP/s), kept as an A/B option
 template <typename T, int PRO>
 int launch_p(const pmi_igemm_args& a, hipStream_t s, int cfg) {
   const int nimg = a.M / (a.H * a.W);
   if (cfg == 0) {          // 8x32 px x 256 ch, 8 waves, one workgroup per CU
     const int tiles = nimg * (a.H / 8) * (a.W / 32) * ((a.N + 255) / 256);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, 4, 2, PRO, PRO == 0>), dim3(tiles), dim3(512), 0, s, a);
+    if (g_incr) hipLaunchKernelGGL((conv3x3_halo_kernel<T, 4, 2, PRO, false, 2, true>), dim3(tiles), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_halo_kernel<T, 4, 2, PRO, PRO == 0>), dim3(tiles), dim3(512), 0, s, a);
   } else if (cfg == 1) {   // 16x32 px x 128 ch, 8 waves
     const int tiles = nimg * (a.H / 16) * (a.W / 32) * ((a.N + 127) / 128);
     hipLaunchKernelGGL((conv3x3_halo_kernel<T, 8, 1, PRO, PRO == 0>), dim3(tiles), dim3(512), 0, s, a);
@@ -288,7 +325,7 @@ int launch_t(const pmi_igemm_args& a, hipStream_t s, int cfg) {
 static int g_force_cfg = -1;   // pmi_set_option(1, cfg): force a tile config where eligible (A/B benchmarking)
 void pmi_conv3x3_force_config(int cfg) { g_force_cfg = cfg; }
 void pmi_conv3x3_use_glds(int) {}      // experiments measured and dropped: direct-to-LDS weights, persistent tiles
-void pmi_conv3x3_persistent(int) {}
+void pmi_conv3x3_persistent(int v) { g_incr = v; }   // option 3 now toggles incremental patch staging (A/B)
 
 // Returns the tile config the halo kernel runs for this shape (0: 8x32 px x 256 ch / 8 waves, 1: 16x32 x 128 / 8 waves,
 // 2: 8x32 x 128 / 4 waves x 2 workgroups per CU) or -1 if the shape needs the generic kernel.

@@ -1,0 +1,1 @@
+"""engine package of perceptor_amd (MI355X-native guided-diffusion hot path)."""

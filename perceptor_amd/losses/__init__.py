@@ -1,3 +1,2 @@
 """Drop-in for ``perceptor.losses`` on the guided-diffusion hot path."""
-from .interface import LossInterface
-from .open_clip import CLIP, OpenCLIP
+from .open_clip import CLIP, LossInterface, OpenCLIP

@@ -15,7 +15,13 @@ import torch.nn.functional as F
 
 from .. import models
 from .._hip import call, ptr
-from .interface import LossInterface
+
+
+class LossInterface(torch.nn.Module):
+    """A differentiable score on images: ``forward(images) -> scalar`` (role of perceptor/losses/interface.py)."""
+
+    def forward(self, images):
+        raise NotImplementedError(type(self).__name__ + ".forward")
 
 
 class _SphericalBase(LossInterface):

@@ -18,7 +18,7 @@ import torch
 
 from ...engine import adm
 from ...utils.synth import synth_state_dict
-from . import diffusion_space
+from ...utils.image_space import images_from_x
 from .predictions import Predictions
 
 
@@ -132,7 +132,7 @@ class GuidedDiffusion(torch.nn.Module):
             raise ValueError("Height must be divisible by 32")
         if w % 8 != 0:
             raise ValueError("Width must be divisible by 32")
-        return diffusion_space.decode(torch.randn(shape).to(self.device))
+        return images_from_x(torch.randn(shape).to(self.device))
 
     def indices(self, indices):
         if isinstance(indices, (float, int)):

@@ -9,7 +9,8 @@ import torch
 from ...engine import sampler, vdiff
 from ...utils.synth import synth_state_dict
 from ..guided_diffusion.guided_diffusion import WeightStore
-from . import diffusion_space, utils
+from ...utils.image_space import images_from_x
+from . import utils
 from .predictions import Predictions
 
 _SPECS = {"yfcc_2": vdiff.yfcc2_spec, "yfcc_1": vdiff.yfcc1_spec, "cc12m_1": vdiff.cc12m1_spec, "cc12m_1_cfg": vdiff.cc12m1_spec,
@@ -81,7 +82,7 @@ class VelocityDiffusion(torch.nn.Module):
         return torch.stack([t[:-1], t[1:]], dim=1)
 
     def random_diffused(self, shape):
-        return diffusion_space.decode(torch.randn(shape)).to(self.device)
+        return images_from_x(torch.randn(shape)).to(self.device)
 
     @staticmethod
     def sigmas_to_ts(sigmas):
