@@ -173,13 +173,21 @@ def main():
                 "frac": round(achieved / PEAK_TFLOPS[a.dtype], 4), "traffic": None,
                 "scope": "whole step (UNet fwd + CLIP fwd+bwd + update), algorithmic FLOP / HIP-event step time"}
         if kernel_events:
-            tot_ms = sum(s.elapsed_time(e) for (s, e, _) in kernel_events)
-            tot_fl = sum(f for (_, _, f) in kernel_events)
-            roof["kernel"] = {"name": "igemm_kernel (conv3x3 implicit GEMM, MFMA)", "launches": len(kernel_events),
+            tot_ms = sum(ev_[0].elapsed_time(ev_[1]) for ev_ in kernel_events)
+            tot_fl = sum(ev_[2] for ev_ in kernel_events)
+            tot_by = sum(ev_[3] for ev_ in kernel_events)
+            roof["kernel"] = {"name": "conv3x3_halo_kernel (3x3 conv implicit GEMM, MFMA)", "launches": len(kernel_events),
                               "avg_ms": round(tot_ms / len(kernel_events), 4),
                               "achieved": round(tot_fl / 1e12 / (tot_ms / 1e3), 2),
                               "frac": round(tot_fl / 1e12 / (tot_ms / 1e3) / PEAK_TFLOPS[a.dtype], 4),
-                              "share_of_step": round(tot_ms / a.steps / step_ms_dev, 3)}
+                              "share_of_step": round(tot_ms / a.steps / step_ms_dev, 3),
+                              "algorithmic_bytes_per_launch": round(tot_by / len(kernel_events)),
+                              "algorithmic_GBps": round(tot_by / 1e9 / (tot_ms / 1e3), 1)}
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+            if a.config == "c5" and os.path.exists(pmc):    # HBM bytes per conv3x3 launch from the committed PMC passes
+                with open(pmc) as f:
+                    roof["traffic"] = json.load(f)["conv3x3_halo_kernel"]["hbm_bytes_per_launch"]
+                roof["traffic_note"] = "profiles/r01_pmc_hbm.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per conv3x3_halo launch, separate rocprofv3 --pmc passes of this command"
         out = {
             "metric": "denoising steps/sec (UNet+CLIP-grad) at 512x512 batch 8" if a.config == "c5" else f"denoising steps/sec ({a.config})",
             "value": round(a.steps / elapsed * world, 4),

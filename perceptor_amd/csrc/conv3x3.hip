@@ -239,6 +239,22 @@ __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_ke
     if (a.R && a.res_up) rrow[i] = (((int64_t)img * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.ldr;
   }
   const float* nbp = a.nbias ? a.nbias + (int64_t)img * (a.ldnb ? a.ldnb : a.N) : nullptr;
+  // The residual pieces of the wave's whole tile are fetched before the first store: interleaving each load with its
+  // store stretched the partial writes of a 128-byte output line over many load latencies, long enough for L2 to evict
+  // the line half-written (PMC WRITE_SIZE showed 2-4x the output bytes on the residual convs).  16-bit residual only.
+  uint2 rv[4][XB][4];
+  if (a.R) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < XB; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wn * 128 + j * 32 + 4 * lhi + 8 * g;
+          rv[j][i][g] = make_uint2(0, 0);
+          if (n < a.N) rv[j][i][g] = *(const uint2*)((const u16*)a.R + rrow[i] + n);
+        }
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float ssum[16], ssq[16];
@@ -260,14 +276,9 @@ __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_ke
           for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
         }
         if (a.R) {
-          if (a.res_f32) {
-            const float4 r = *(const float4*)((const float*)a.R + rrow[i] + n);
-            v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-          } else {
-            const uint2 r = *(const uint2*)((const u16*)a.R + rrow[i] + n);
-            v[0] += T::to_f((u16)(r.x & 0xffff)); v[1] += T::to_f((u16)(r.x >> 16));
-            v[2] += T::to_f((u16)(r.y & 0xffff)); v[3] += T::to_f((u16)(r.y >> 16));
-          }
+          const uint2 r = rv[j][i][g];
+          v[0] += T::to_f((u16)(r.x & 0xffff)); v[1] += T::to_f((u16)(r.x >> 16));
+          v[2] += T::to_f((u16)(r.y & 0xffff)); v[3] += T::to_f((u16)(r.y >> 16));
         }
         const int64_t o = mpix[i] * a.ldd + n;
         if (a.out_f32) *(float4*)((float*)a.D + o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -297,9 +308,6 @@ int launch_p(const pmi_igemm_args& a, hipStream_t s, int cfg) {
   } else if (cfg == 1) {   // 16x32 px x 128 ch, 8 waves
     const int tiles = nimg * (a.H / 16) * (a.W / 32) * ((a.N + 127) / 128);
     hipLaunchKernelGGL((conv3x3_halo_kernel<T, 8, 1, PRO, PRO == 0>), dim3(tiles), dim3(512), 0, s, a);
-  } else if (cfg == 3) {   // 8x32 px x 256 ch, 4 waves of 128 px x 128 ch, one wave per SIMD (512 registers each)
-    const int tiles = nimg * (a.H / 8) * (a.W / 32) * ((a.N + 255) / 256);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, 2, 2, PRO, true, 4>), dim3(tiles), dim3(256), 0, s, a);
   } else {                 // 8x32 px x 128 ch, 4 waves, two workgroups per CU overlap each other's staging / epilogue
     const int tiles = nimg * (a.H / 8) * (a.W / 32) * ((a.N + 127) / 128);
     hipLaunchKernelGGL((conv3x3_halo_kernel<T, 4, 1, PRO, false>), dim3(tiles), dim3(256), 0, s, a);
@@ -330,14 +338,13 @@ void pmi_conv3x3_persistent(int v) { g_incr = v; }   // option 3 now toggles inc
 // Returns the tile config the halo kernel runs for this shape (0: 8x32 px x 256 ch / 8 waves, 1: 16x32 x 128 / 8 waves,
 // 2: 8x32 x 128 / 4 waves x 2 workgroups per CU) or -1 if the shape needs the generic kernel.
 extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
-  if (a->taps != 9 || a->stride != 1 || a->batch > 1) return -1;
+  if (a->taps != 9 || a->stride != 1 || a->batch > 1 || (a->R && a->res_f32)) return -1;
   const int Cin = a->C0 + a->C1;
   if ((Cin % 64) || (a->C0 % 64) || (a->W % 32) || (a->H % 8) || (a->N % 128)) return -1;
   const bool ok0 = (a->N % 256) == 0 || a->N >= 256, ok1 = (a->H % 16) == 0;
   if (g_force_cfg == 0 && ok0) return 0;
   if (g_force_cfg == 1 && ok1) return 1;
   if (g_force_cfg == 2) return 2;
-  if (g_force_cfg == 3 && (a->N % 256) == 0) return 3;
   // One 8-wave workgroup per CU: a grid well below 256 workgroups leaves CUs idle; such layers (<= 32x32 feature maps
   // at batch 8) go to the generic kernel, whose 128x128 tiles (and split-K) fill the chip.
   const int nimg = a->M / (a->H * a->W);

@@ -26,7 +26,7 @@ def set_halo(enabled: bool) -> None:
     _hip.lib().pmi_set_option(0, int(enabled))
 
 
-# bench.py sets this to a list to time every conv3x3 launch with HIP events on the launch stream
+# bench.py sets this to a list to time every conv3x3_halo_kernel launch with HIP events on the launch stream
 KERNEL_EVENTS = None
 
 
@@ -126,12 +126,16 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
             st = _empty((m // a.hw, rows, lin.n_p, 2), torch.float32, a0.device)
             a.stats, a.stats_p = ptr(st), rows
             out._pmi_stats = (st, rows)
-    if KERNEL_EVENTS is not None and lin.taps == 9:
+    if KERNEL_EVENTS is not None and lin.taps == 9 and HALO_ENABLED and _hip.lib().pmi_conv3x3_halo_config(C.byref(a)) >= 0:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         call("pmi_igemm", C.byref(a))
         e1.record()
-        KERNEL_EVENTS.append((e0, e1, 2.0 * m * lin.cout * lin.cin * lin.taps))
+        # algorithmic HBM bytes of the launch: input read once, packed weights, output written once, residual read once
+        nbytes = (a0.numel() + (a1.numel() if a1 is not None else 0)) * 2 + lin.w.numel() * 2 + out.numel() * out.element_size()
+        if residual is not None:
+            nbytes += (residual.numel() if not res_up else residual.numel()) * residual.element_size()
+        KERNEL_EVENTS.append((e0, e1, 2.0 * m * lin.cout * lin.cin * lin.taps, float(nbytes)))
         return out
     call("pmi_igemm", C.byref(a))
     return out
