@@ -52,6 +52,7 @@ def parse():
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-events", action="store_true")
+    p.add_argument("--dump-kernels", default=None, help="write per-launch (ms, GFLOP, MB) of the timed conv3x3 launches of the last step to this file")
     return p.parse_args()
 
 
@@ -183,6 +184,13 @@ def main():
                               "share_of_step": round(tot_ms / a.steps / step_ms_dev, 3),
                               "algorithmic_bytes_per_launch": round(tot_by / len(kernel_events)),
                               "algorithmic_GBps": round(tot_by / 1e9 / (tot_ms / 1e3), 1)}
+            if a.dump_kernels:
+                per = len(kernel_events) // a.steps
+                with open(a.dump_kernels, "w") as f:
+                    for k in range(per):
+                        evs = [kernel_events[st * per + k] for st in range(a.steps)]
+                        ms = sum(e[0].elapsed_time(e[1]) for e in evs) / a.steps
+                        f.write(f"{k:3d} {ms:8.4f} ms {evs[0][2] / 1e9:10.1f} GFLOP {evs[0][3] / 1e6:9.1f} MB {evs[0][2] / 1e9 / ms:8.1f} TFLOP/s {evs[0][3] / 1e6 / ms:8.1f} GB/s {evs[0][4]}\n")
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
             if a.config == "c5" and os.path.exists(pmc):    # HBM bytes per conv3x3 launch from the committed PMC passes
                 with open(pmc) as f:

@@ -57,6 +57,12 @@ __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_ke
   const int ty = logical % tiles_y;
   const int img = logical / tiles_y;
   const int y0 = ty * TH, x0 = tx * 32, n0 = tn * BN;
+#ifdef PMI_STAMPS
+#define STAMP(k) do { if (tid == 0 && a.ws) ((long long*)a.ws)[(int64_t)blockIdx.x * 8 + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+  STAMP(0);
 
   const int Cin = a.C0 + a.C1;
   const int Hv = a.H, Wv = a.W;                         // conv runs on the (possibly upsampled) H x W grid
@@ -179,6 +185,7 @@ __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_ke
   store_patch(smem);
   store_w(0);
   __syncthreads();
+  STAMP(1);
   int cur = 0;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const char* const patch = smem + (INCR ? (chunk & 1) * PATCH_BYTES : 0);
@@ -224,12 +231,24 @@ __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_ke
     }
   }
 
+  STAMP(2);
   // ---- epilogue: lane = pixel, registers = 4 consecutive output channels x 4 groups per 32x32 block ----
   float* const stat = (float*)smem;            // [BN][2] per-channel (sum, sumsq) of this tile (LDS is free now)
-  if (a.stats) {
-    for (int c = tid; c < 2 * BN; c += NT) stat[c] = 0.f;
-    __syncthreads();
+  float* const bsm = stat + 2 * BN;            // [BN] bias + per-sample bias of the tile's channels
+  // The biases go through LDS: as per-lane global loads inside the store loop they cannot be hoisted above the preceding
+  // stores (may alias), which serialised 32 load->store round trips per wave (15 us of a 95 us tile, measured).
+  for (int c = tid; c < BN; c += NT) {
+    const int n = n0 + c;
+    float b = 0.f;
+    if (n < a.N) {
+      if (a.bias) b = a.bias[n];
+      if (a.nbias) b += a.nbias[(int64_t)img * (a.ldnb ? a.ldnb : a.N) + n];
+    }
+    bsm[c] = b;
   }
+  if (a.stats)
+    for (int c = tid; c < 2 * BN; c += NT) stat[c] = 0.f;
+  __syncthreads();
   int64_t mpix[XB], rrow[XB];
 #pragma unroll
   for (int i = 0; i < XB; ++i) {
@@ -238,7 +257,6 @@ __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_ke
     rrow[i] = mpix[i] * a.ldr;
     if (a.R && a.res_up) rrow[i] = (((int64_t)img * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.ldr;
   }
-  const float* nbp = a.nbias ? a.nbias + (int64_t)img * (a.ldnb ? a.ldnb : a.N) : nullptr;
   // The residual pieces of the wave's whole tile are fetched before the first store: interleaving each load with its
   // store stretched the partial writes of a 128-byte output line over many load latencies, long enough for L2 to evict
   // the line half-written (PMC WRITE_SIZE showed 2-4x the output bytes on the residual convs).  16-bit residual only.
@@ -269,8 +287,7 @@ __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_ke
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * a.alpha;
-        if (a.bias) { const float4 b = *(const float4*)(a.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-        if (nbp) { const float4 b = *(const float4*)(nbp + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+        { const float4 b = *(const float4*)(bsm + (n - n0)); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
         if (a.act != PMI_ACT_NONE) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
@@ -289,12 +306,22 @@ __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_ke
     }
     if (a.stats) stats_block_to_lds(ssum, ssq, stat, wn * 128 + j * 32, lane);
   }
+  STAMP(3);
   if (a.stats) {
     __syncthreads();
     float* o = a.stats + (((int64_t)img * a.stats_p + ty * tiles_x + tx) * a.N + n0) * 2;
     for (int c = tid; c < 2 * BN; c += NT)
       if (n0 + (c >> 1) < a.N) o[c] = stat[c];
   }
+#ifdef PMI_STAMPS
+  __syncthreads();
+  if (tid == 0 && a.ws) {
+    ((long long*)a.ws)[(int64_t)blockIdx.x * 8 + 4] = (long long)wall_clock64();
+    unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    ((long long*)a.ws)[(int64_t)blockIdx.x * 8 + 5] = ((long long)xcc << 32) | hwid;
+  }
+#endif
 }
 
 static int g_incr = 0;   // measured: no gain over the chunk-boundary staging (876 vs 943 TFLOP/s), kept as an A/B option
@@ -349,9 +376,12 @@ extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
   // at batch 8) go to the generic kernel, whose 128x128 tiles (and split-K) fill the chip.
   const int nimg = a->M / (a->H * a->W);
   const int px_tiles8 = nimg * (a->H / 8) * (a->W / 32);
+  // Two 4-wave workgroups per CU (cfg 2) beat one 8-wave workgroup (cfg 0/1) by 5-9 % on every UNet shape measured:
+  // all workgroups of a launch run in lockstep, so the epilogues of all 256 CUs hit HBM at once (11-20 us of a 60-100 us
+  // tile, measured with in-kernel timestamps); with two workgroups per CU one computes while the other drains.
+  if (px_tiles8 * (a->N / 128) >= 384) return 2;
   if ((a->N % 256) == 0) return px_tiles8 * (a->N / 256) >= 192 ? 0 : -1;
   if (ok1 && (px_tiles8 / 2) * (a->N / 128) >= 192) return 1;
-  if (px_tiles8 * (a->N / 128) >= 384) return 2;
   return -1;
 }
 

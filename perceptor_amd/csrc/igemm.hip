@@ -209,9 +209,20 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
     float ssum[16], ssq[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
-    // all residual pieces of the block are fetched before its first store, so the partial writes of an output line
-    // reach L2 back to back instead of one load latency apart (see conv3x3.hip)
-    float4 rv[2][4];
+    // biases and residual pieces of the block are fetched before its first store: loads inside the store loop cannot be
+    // hoisted above the preceding stores (may alias) and serialise one round trip per store (see conv3x3.hip)
+    float4 rv[2][4], bv[4], nbv[2][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = n0 + wc * 64 + j * 32 + 4 * lhi + 8 * g;
+      bv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.bias && n < a.N) bv[g] = *(const float4*)(a.bias + n);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        nbv[i][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nbp[i] && n < a.N) nbv[i][g] = *(const float4*)(nbp[i] + n);
+      }
+    }
     if (a.R) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -239,14 +250,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * a.alpha;
-        if (a.bias) {
-          const float4 b = *(const float4*)(a.bias + n);
-          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        }
-        if (nbp[i]) {
-          const float4 b = *(const float4*)(nbp[i] + n);
-          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        }
+        v[0] += bv[g].x + nbv[i][g].x; v[1] += bv[g].y + nbv[i][g].y; v[2] += bv[g].z + nbv[i][g].z; v[3] += bv[g].w + nbv[i][g].w;
         if (a.act != PMI_ACT_NONE) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);

@@ -28,6 +28,7 @@ def set_halo(enabled: bool) -> None:
 
 # bench.py sets this to a list to time every conv3x3_halo_kernel launch with HIP events on the launch stream
 KERNEL_EVENTS = None
+DEBUG_WS = None      # tools/conv_probe.py --stamps: int64 buffer the PMI_STAMPS build of conv3x3.hip writes phase timestamps to
 
 
 def _empty(shape, dtype, device):
@@ -126,6 +127,8 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
             st = _empty((m // a.hw, rows, lin.n_p, 2), torch.float32, a0.device)
             a.stats, a.stats_p = ptr(st), rows
             out._pmi_stats = (st, rows)
+    if DEBUG_WS is not None:
+        a.ws = ptr(DEBUG_WS)
     if KERNEL_EVENTS is not None and lin.taps == 9 and HALO_ENABLED and _hip.lib().pmi_conv3x3_halo_config(C.byref(a)) >= 0:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -135,7 +138,9 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
         nbytes = (a0.numel() + (a1.numel() if a1 is not None else 0)) * 2 + lin.w.numel() * 2 + out.numel() * out.element_size()
         if residual is not None:
             nbytes += (residual.numel() if not res_up else residual.numel()) * residual.element_size()
-        KERNEL_EVENTS.append((e0, e1, 2.0 * m * lin.cout * lin.cin * lin.taps, float(nbytes)))
+        desc = f"{a.H}x{a.W} {c0}+{c1}->{lin.cout} cfg{_hip.lib().pmi_conv3x3_halo_config(C.byref(a))}" \
+               f"{' pro' if prologue is not None else ''}{' res' if residual is not None else ''}{' up' if up else ''}{' stats' if want_stats else ''}"
+        KERNEL_EVENTS.append((e0, e1, 2.0 * m * lin.cout * lin.cin * lin.taps, float(nbytes), desc))
         return out
     call("pmi_igemm", C.byref(a))
     return out

@@ -11,7 +11,7 @@ p.add_argument("--n", type=int, default=8); p.add_argument("--hw", type=int, def
 p.add_argument("--cin", type=int, default=256); p.add_argument("--cout", type=int, default=256)
 p.add_argument("--iters", type=int, default=20); p.add_argument("--dtype", default="bf16")
 p.add_argument("--halo", type=int, default=1); p.add_argument("--pro", type=int, default=0)
-p.add_argument("--rounds", type=int, default=3); p.add_argument("--cfg", type=int, default=-1); p.add_argument("--glds", type=int, default=1); p.add_argument("--dbg", type=int, default=0); p.add_argument("--persist", type=int, default=1)
+p.add_argument("--rounds", type=int, default=3); p.add_argument("--cfg", type=int, default=-1); p.add_argument("--glds", type=int, default=1); p.add_argument("--dbg", type=int, default=0); p.add_argument("--persist", type=int, default=1); p.add_argument("--stamps", type=int, default=0); p.add_argument("--res", type=int, default=0); p.add_argument("--stats", type=int, default=0)
 a = p.parse_args()
 dev = torch.device("cuda:0")
 dt = dtype_code(a.dtype)
@@ -31,13 +31,47 @@ _hip.lib().pmi_set_option(3, a.persist)
 STAMP = None
 for halo in ([a.halo] if a.halo in (0, 1) else [0, 1]):
     ops.set_halo(bool(halo))
-    out = ops.igemm(x, lin, prologue=pro)
+    res = torch.randn(a.n, a.hw, a.hw, a.cout, generator=g).to(td).to(dev) if a.res else None
+    out = ops.igemm(x, lin, prologue=pro, residual=res, want_stats=bool(a.stats))
     torch.cuda.synchronize()
     for r in range(a.rounds):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.iters):
-            ops.igemm(x, lin, prologue=pro, out=out)
+            ops.igemm(x, lin, prologue=pro, out=out, residual=res, want_stats=bool(a.stats))
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
         print(f"halo={halo} cfg={a.cfg} glds={a.glds} dbg={a.dbg} persist={a.persist} n={a.n} hw={a.hw} cin={a.cin} cout={a.cout} pro={a.pro}: {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s", flush=True)
+
+if a.stamps:
+    # needs conv3x3.hip built with -DPMI_STAMPS: per-workgroup wall_clock64 (100 MHz) at entry / first barrier / main loop end /
+    # epilogue end / exit, plus HW_ID and XCC_ID
+    ops.set_halo(True)
+    ws = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
+    ops.DEBUG_WS = ws
+    ops.igemm(x, lin, prologue=pro, out=out, residual=res, want_stats=bool(a.stats))
+    torch.cuda.synchronize()
+    ops.DEBUG_WS = None
+    st = ws.cpu().view(-1, 8)
+    st = st[st[:, 0] > 0]
+    t = st[:, :5].double()
+    t0 = t[:, 0].min()
+    us = lambda v: float(v) * 0.01
+    print(f"workgroups {len(st)}  kernel span {us(t[:, 4].max() - t0):.1f} us")
+    for nm, k0, k1 in (("prologue", 0, 1), ("mainloop", 1, 2), ("epilogue", 2, 3), ("stats+exit", 3, 4), ("total", 0, 4)):
+        d = t[:, k1] - t[:, k0]
+        print(f"  {nm:10s} mean {us(d.mean()):8.2f} us  min {us(d.min()):8.2f}  max {us(d.max()):8.2f}")
+    hw = st[:, 5]
+    cu = ((hw >> 32) & 0xf) * 1024 + ((hw >> 13) & 0x7) * 64 + ((hw >> 8) & 0xf) * 4 + ((hw >> 12) & 1)   # xcc, se, cu, sh (ids only used to group)
+    ids = cu.unique()
+    busy = torch.zeros(len(ids), dtype=torch.float64)
+    gaps = []
+    for i, c in enumerate(ids):
+        rows = t[cu == c]
+        rows = rows[rows[:, 0].argsort()]
+        busy[i] = (rows[:, 4] - rows[:, 0]).sum()
+        if len(rows) > 1:
+            gaps.append((rows[1:, 0] - rows[:-1, 4]).mean())
+    span = t[:, 4].max() - t0
+    print(f"  distinct CU ids {len(ids)}  mean busy fraction {float(busy.mean() / span):.3f}  mean gap between consecutive workgroups on a CU {us(torch.tensor(gaps).mean()) if gaps else 0:.2f} us")
+    print(f"  first start spread {us(t[:, 0].sort().values[min(255, len(t) - 1)] - t0):.2f} us; last-wave tail: 90th pct end {us(t[:, 4].quantile(0.9) - t0):.1f} us vs span")
