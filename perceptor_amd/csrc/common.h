@@ -41,6 +41,19 @@ struct BF16 {
   }
 };
 
+// Raw buffer loads: an offset with the top bit set is out of range for every resource made here (num_records < 2^31),
+// and out-of-range loads return zeros -- a predicated load without a branch.
+typedef unsigned int pmi_u32x4 __attribute__((ext_vector_type(4)));
+#define PMI_BUF_OOB 0x80000000u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int64_t bytes) {
+  const int n = bytes > 0x7ffffff0ll ? 0x7ffffff0 : (int)bytes;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, n, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t voffset, uint32_t soffset) {
+  const pmi_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, 0);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 template <typename T>
 __device__ __forceinline__ void unpack8(uint4 v, float* f) {
   const uint32_t w[4] = {v.x, v.y, v.z, v.w};

@@ -24,14 +24,14 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((ch
 
 // PRO: 0 none, else 1 + PMI_ACT_* of the fused GroupNorm-apply prologue.  EARLY: prefetch the next patch into registers
 // under the last tap's MFMAs (only when the register budget allows and there is no second workgroup to hide the latency).
-// XB: image rows (32-pixel MFMA blocks) per wave.  XB = 2 with 8 waves (two waves per SIMD, 256 registers each) or XB = 4
-// with 4 waves (ONE wave per SIMD owning the whole 512-register file: 256 accumulators, 0.5 instead of 0.75 LDS fragment
-// reads per MFMA, nothing to arbitrate on the SIMD).
-// INCR: two patch buffers; the next 64-channel chunk's patch is staged piecewise (one 16-byte piece per thread per tap,
-// GroupNorm prologue applied on the way) under taps 0..NPI-1 of the current chunk, so there is no bubble (two barriers + an
-// exposed load + ~500 VALU instructions per thread) at chunk boundaries and no 24-register patch prefetch.
-template <typename T, int WM, int WN, int PRO, bool EARLY, int XB = 2, bool INCR = false>
-__global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_kernel(const pmi_igemm_args a) {
+//
+// Every global read of the main loop is a raw buffer load whose offset is set out of range for padding pixels (the
+// hardware returns zeros): no divergent branch around a load.  With `if (inside) v = load` the compiler lost count of the
+// loads in flight at every branch join and fell back to s_waitcnt vmcnt(0) -- right after issuing the next tap's weight
+// loads, i.e. one exposed L2 round trip per tap in front of the MFMAs.
+template <typename T, int WM, int WN, int PRO, bool EARLY>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi_igemm_args a) {
+  constexpr int XB = 2;                                // image rows (32-pixel MFMA blocks) per wave
   constexpr int TH = WM * XB;                          // image rows per tile
   constexpr int NT = WM * WN * 64;                     // threads per workgroup
   constexpr int RPI = NT / 8;                          // tile rows staged per pass (8 threads x 16 B per 128-B row)
@@ -39,11 +39,10 @@ __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_ke
   constexpr int PP = (TH + 2) * PW;                    // patch pixels
   constexpr int NPI = (PP + RPI - 1) / RPI;            // 16-byte patch chunks per thread
   constexpr int NWI = BN / RPI;                        // 16-byte weight chunks per thread per tap
-  constexpr int PATCH_BYTES = PP * 128;
+  constexpr int PATCH_BYTES = NPI * RPI * 128;         // padded to whole staging passes: no bounds test on the LDS writes
   constexpr int WBYTES = BN * 128;
-  constexpr int NPB = INCR ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) char smem[NPB * PATCH_BYTES + 2 * WBYTES];
-  char* const wbuf = smem + NPB * PATCH_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[PATCH_BYTES + 2 * WBYTES];
+  char* const wbuf = smem + PATCH_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -66,13 +65,18 @@ __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_ke
 
   const int Cin = a.C0 + a.C1;
   const int Hv = a.H, Wv = a.W;                         // conv runs on the (possibly upsampled) H x W grid
-  const u16* A0 = (const u16*)a.A0;
-  const u16* A1 = (const u16*)a.A1;
-  const u16* Bw = (const u16*)a.B;
   const int sc = tid & 7;                              // 16-byte chunk (8 channels) this thread stages, fixed
+  // per-image views of the two input tensors and the weight rows of this tile (32-bit offsets inside each)
+  const int64_t img_px = (int64_t)a.Hin * a.Win;
+  const u16* const A0i = (const u16*)a.A0 + (int64_t)img * img_px * a.lda0;
+  const u16* const A1i = a.A1 ? (const u16*)a.A1 + (int64_t)img * img_px * a.lda1 : A0i;
+  const int64_t bytes0 = ((img_px - 1) * a.lda0 + a.C0) * 2;
+  const int64_t bytes1 = a.A1 ? ((img_px - 1) * a.lda1 + a.C1) * 2 : 0;
+  const int nrows = min(BN, a.N - n0);
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc((const u16*)a.B + (int64_t)n0 * a.ldb, ((int64_t)(nrows - 1) * a.ldb + a.K) * 2);
 
-  // ---- patch staging plan: source pixel index per staged chunk (-1 = zero padding) ----
-  int poff[NPI];
+  // ---- patch staging plan: source pixel (inside the image) per staged chunk, -1 = zero padding ----
+  int ppix[NPI];
 #pragma unroll
   for (int i = 0; i < NPI; ++i) {
     const int pp = (tid >> 3) + RPI * i;
@@ -82,88 +86,55 @@ __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_ke
       int sy = y0 - 1 + py, sx = x0 - 1 + px;
       if (sy >= 0 && sy < Hv && sx >= 0 && sx < Wv) {
         if (a.up) { sy >>= 1; sx >>= 1; }
-        off = (img * a.Hin + sy) * a.Win + sx;
+        off = sy * a.Win + sx;
       }
     }
-    poff[i] = off;
+    ppix[i] = off;
   }
-  int wrow[NWI];                                       // element offset of this thread's weight chunk (fits 31 bits: Cout*9*Cin)
+  uint32_t wvo[NWI];                                   // byte offset of this thread's weight chunks inside the tile's rows
 #pragma unroll
-  for (int i = 0; i < NWI; ++i) {
-    const int n = n0 + (tid >> 3) + RPI * i;
-    wrow[i] = n < a.N ? n * a.ldb + sc * 8 : -1;
-  }
+  for (int i = 0; i < NWI; ++i) wvo[i] = (uint32_t)(((tid >> 3) + RPI * i) * a.ldb + sc * 8) * 2u;
 
   uint4 pr[NPI], wr[NWI];
   float ga[8], gb[8];
   auto load_patch = [&](int chunk) {
-    const int ci = chunk * 64 + sc * 8;
-    const bool second = ci >= a.C0;
-    const u16* base = second ? A1 + (ci - a.C0) : A0 + ci;
-    const int ld = second ? a.lda1 : a.lda0;
+    const int cbase = chunk * 64;
+    const bool second = cbase >= a.C0;                  // wave-uniform: C0 is a multiple of 64
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(second ? A1i : A0i, second ? bytes1 : bytes0);
+    const uint32_t ldb2 = (uint32_t)(second ? a.lda1 : a.lda0) * 2u;
+    const uint32_t so = (uint32_t)(cbase - (second ? a.C0 : 0)) * 2u;
 #pragma unroll
     for (int i = 0; i < NPI; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (poff[i] >= 0) v = *(const uint4*)(base + (int64_t)poff[i] * ld);
-      pr[i] = v;
+      const uint32_t vo = ppix[i] >= 0 ? (uint32_t)ppix[i] * ldb2 + (uint32_t)sc * 16u : PMI_BUF_OOB;
+      pr[i] = buf_load16(rs, vo, so);
     }
     if (PRO) {
-      const float* pa = a.pro_a + (int64_t)img * Cin + ci;
-      const float* pb = a.pro_b + (int64_t)img * Cin + ci;
+      const float* pa = a.pro_a + (int64_t)img * Cin + cbase + sc * 8;
+      const float* pb = a.pro_b + (int64_t)img * Cin + cbase + sc * 8;
       *(float4*)ga = *(const float4*)pa; *(float4*)(ga + 4) = *(const float4*)(pa + 4);
       *(float4*)gb = *(const float4*)pb; *(float4*)(gb + 4) = *(const float4*)(pb + 4);
     }
   };
-  auto piece_off = [&](int i) -> int {                // source pixel of patch piece i (any i, computed, not looked up)
-    const int pp = (tid >> 3) + RPI * i;
-    if (pp >= PP) return -1;
-    const int py = pp / PW, px = pp - py * PW;
-    int sy = y0 - 1 + py, sx = x0 - 1 + px;
-    if (sy < 0 || sy >= Hv || sx < 0 || sx >= Wv) return -1;
-    if (a.up) { sy >>= 1; sx >>= 1; }
-    return (img * a.Hin + sy) * a.Win + sx;
-  };
-  auto store_piece = [&](char* pbuf, int i, uint4 v, int off) {
-    const int pp = (tid >> 3) + RPI * i;
-    if (pp < PP) {
-      if (PRO && off >= 0) {
+  auto store_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+      uint4 v = pr[i];
+      if (PRO) {                                        // GroupNorm-apply + activation; zero padding stays zero
         float f[8];
         unpack8<T>(v, f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = act_apply(f[e] * ga[e] + gb[e], PRO - 1);
         v = pack8<T>(f);
+        const uint32_t keep = ppix[i] >= 0 ? 0xffffffffu : 0u;
+        v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
       }
-      *(uint4*)(pbuf + swz(pp, sc)) = v;
+      *(uint4*)(smem + swz((tid >> 3) + RPI * i, sc)) = v;
     }
-  };
-  auto store_patch = [&](char* pbuf) {
-#pragma unroll
-    for (int i = 0; i < NPI; ++i) store_piece(pbuf, i, pr[i], poff[i]);
-  };
-  // INCR: piece i of chunk `chunk` (this thread's 16 bytes of patch pixel srow + RPI*i) and its prologue coefficients
-  auto load_piece = [&](int chunk, int off) -> uint4 {
-    const int ci = chunk * 64 + sc * 8;
-    const bool second = ci >= a.C0;
-    const u16* base = second ? A1 + (ci - a.C0) : A0 + ci;
-    const int ld = second ? a.lda1 : a.lda0;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (off >= 0) v = *(const uint4*)(base + (int64_t)off * ld);
-    if (PRO) {
-      const float* pa = a.pro_a + (int64_t)img * Cin + ci;
-      const float* pb = a.pro_b + (int64_t)img * Cin + ci;
-      *(float4*)ga = *(const float4*)pa; *(float4*)(ga + 4) = *(const float4*)(pa + 4);
-      *(float4*)gb = *(const float4*)pb; *(float4*)(gb + 4) = *(const float4*)(pb + 4);
-    }
-    return v;
   };
   auto load_w = [&](int chunk, int tap) {
-    const int64_t koff = (int64_t)tap * Cin + chunk * 64;
+    const uint32_t so = (uint32_t)(tap * Cin + chunk * 64) * 2u;
 #pragma unroll
-    for (int i = 0; i < NWI; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (wrow[i] >= 0) v = *(const uint4*)(Bw + (int64_t)wrow[i] + koff);
-      wr[i] = v;
-    }
+    for (int i = 0; i < NWI; ++i) wr[i] = buf_load16(rsrc_w, wvo[i], so);
   };
   auto store_w = [&](int buf) {
     char* wb = wbuf + buf * WBYTES;
@@ -179,56 +150,61 @@ __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_ke
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  auto mma_tap = [&](int tap, int cur) {
+    const int dy = tap / 3, dx = tap - dy * 3;          // patch row/col offset (tap - 1 + halo 1)
+    const char* wb = wbuf + cur * WBYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int ch = kk * 2 + lhi;
+      uint4 xf[XB], wf[4];
+#pragma unroll
+      for (int i = 0; i < XB; ++i) xf[i] = *(const uint4*)(smem + swz((XB * wm + i + dy) * PW + l31 + dx, ch));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[j] = *(const uint4*)(wb + swz(wn * 128 + j * 32 + l31, ch));
+#pragma unroll
+      for (int i = 0; i < XB; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma32(wf[j], xf[i], acc[i][j]);
+    }
+  };
+
   const int nchunks = Cin / 64;
   load_patch(0);
   load_w(0, 0);
-  store_patch(smem);
+  store_patch();
   store_w(0);
   __syncthreads();
   STAMP(1);
   int cur = 0;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
-    const char* const patch = smem + (INCR ? (chunk & 1) * PATCH_BYTES : 0);
-    char* const patch_next = smem + (INCR ? ((chunk + 1) & 1) * PATCH_BYTES : 0);
+    // taps 0..7: the next tap's weights travel global -> registers under this tap's MFMAs, then registers -> the other buffer
 #pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-      const bool last_tap = tap == 8;
-      const bool more_chunks = chunk + 1 < nchunks;
-      const bool has_next = !last_tap || more_chunks;
-      if (has_next) load_w(last_tap ? chunk + 1 : chunk, last_tap ? 0 : tap + 1);
-      uint4 piece = make_uint4(0, 0, 0, 0);
-      const bool stage = INCR && tap < NPI && more_chunks;
-      int poff_piece = -1;
-      if (stage) { poff_piece = piece_off(tap); piece = load_piece(chunk + 1, poff_piece); }
-      // Without a prologue the next patch is prefetched into registers under the MFMAs of the last tap.  With the fused
-      // GroupNorm prologue that would push the kernel over 256 VGPRs (spills), so the loads are issued after the MFMAs
-      // instead (one exposed load latency per 64-channel chunk = per 288 MFMAs).
-      if (!INCR && EARLY && last_tap && more_chunks) load_patch(chunk + 1);
-      const int dy = tap / 3, dx = tap - dy * 3;        // patch row/col offset (tap - 1 + halo 1)
-      const char* wb = wbuf + cur * WBYTES;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int ch = kk * 2 + lhi;
-        uint4 xf[XB], wf[4];
-#pragma unroll
-        for (int i = 0; i < XB; ++i) xf[i] = *(const uint4*)(patch + swz((XB * wm + i + dy) * PW + l31 + dx, ch));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = *(const uint4*)(wb + swz(wn * 128 + j * 32 + l31, ch));
-#pragma unroll
-        for (int i = 0; i < XB; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma32(wf[j], xf[i], acc[i][j]);
-      }
-      if (has_next) store_w(cur ^ 1);
-      if (stage) store_piece(patch_next, tap, piece, poff_piece);
-      if (!INCR && last_tap && more_chunks) {
-        if (!EARLY) load_patch(chunk + 1);
-        __syncthreads();          // every wave is done reading the current patch
-        store_patch(smem);
-      }
+    for (int tap = 0; tap < 8; ++tap) {
+      load_w(chunk, tap + 1);
+      __builtin_amdgcn_sched_barrier(0);   // keep the loads in front of the MFMAs (the scheduler sinks them to their use)
+      mma_tap(tap, cur);
+      __builtin_amdgcn_sched_barrier(0);
+      store_w(cur ^ 1);
       __syncthreads();
       cur ^= 1;
     }
+    // tap 8 also brings in the next 64-channel patch.  Without a prologue it is prefetched into registers under the MFMAs;
+    // with the fused GroupNorm prologue that would exceed 256 VGPRs, so it is loaded after them (the second workgroup
+    // on the CU covers the latency).  After the last chunk the weight load re-reads tile (0, 0): harmless, never used.
+    const bool more = chunk + 1 < nchunks;
+    load_w(more ? chunk + 1 : 0, 0);
+    if (EARLY && more) load_patch(chunk + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tap(8, cur);
+    __builtin_amdgcn_sched_barrier(0);
+    store_w(cur ^ 1);
+    if (more) {
+      if (!EARLY) load_patch(chunk + 1);
+      __syncthreads();          // every wave is done reading the current patch
+      store_patch();
+    }
+    __syncthreads();
+    cur ^= 1;
   }
 
   STAMP(2);
@@ -324,14 +300,12 @@ __global__ __launch_bounds__(WM * WN * 64, XB == 4 ? 1 : 2) void conv3x3_halo_ke
 #endif
 }
 
-static int g_incr = 0;   // measured: no gain over the chunk-boundary staging (876 vs 943 TFLOP/s), kept as an A/B option
 template <typename T, int PRO>
 int launch_p(const pmi_igemm_args& a, hipStream_t s, int cfg) {
   const int nimg = a.M / (a.H * a.W);
   if (cfg == 0) {          // 8x32 px x 256 ch, 8 waves, one workgroup per CU
     const int tiles = nimg * (a.H / 8) * (a.W / 32) * ((a.N + 255) / 256);
-    if (g_incr) hipLaunchKernelGGL((conv3x3_halo_kernel<T, 4, 2, PRO, false, 2, true>), dim3(tiles), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((conv3x3_halo_kernel<T, 4, 2, PRO, PRO == 0>), dim3(tiles), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, 4, 2, PRO, PRO == 0>), dim3(tiles), dim3(512), 0, s, a);
   } else if (cfg == 1) {   // 16x32 px x 128 ch, 8 waves
     const int tiles = nimg * (a.H / 16) * (a.W / 32) * ((a.N + 127) / 128);
     hipLaunchKernelGGL((conv3x3_halo_kernel<T, 8, 1, PRO, PRO == 0>), dim3(tiles), dim3(512), 0, s, a);
@@ -359,8 +333,8 @@ int launch_t(const pmi_igemm_args& a, hipStream_t s, int cfg) {
 // Returns the config the halo kernel can run (0: 8x32 x 256ch, 1: 16x32 x 128ch) or -1 if the shape needs the generic kernel.
 static int g_force_cfg = -1;   // pmi_set_option(1, cfg): force a tile config where eligible (A/B benchmarking)
 void pmi_conv3x3_force_config(int cfg) { g_force_cfg = cfg; }
-void pmi_conv3x3_use_glds(int) {}      // experiments measured and dropped: direct-to-LDS weights, persistent tiles
-void pmi_conv3x3_persistent(int v) { g_incr = v; }   // option 3 now toggles incremental patch staging (A/B)
+void pmi_conv3x3_use_glds(int) {}      // experiments measured and dropped: direct-to-LDS weights, persistent tiles, start stagger
+void pmi_conv3x3_persistent(int) {}    // incremental patch staging: measured (876 vs 943 TFLOP/s) and dropped
 
 // Returns the tile config the halo kernel runs for this shape (0: 8x32 px x 256 ch / 8 waves, 1: 16x32 x 128 / 8 waves,
 // 2: 8x32 x 128 / 4 waves x 2 workgroups per CU) or -1 if the shape needs the generic kernel.

@@ -72,10 +72,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
     brow[i] = n < a.N ? (int64_t)n * a.ldb : -1;
   }
 
-  uint4 ra[4], rb[4];
+  uint4 ra0[4], rb0[4], ra1[4], rb1[4];   // two register sets: global loads run two k-tiles ahead of the MFMAs
   int tap_u = 0, ci_u = 0;  // KFAST: uniform (tap, channel) of the next k-tile to load
 
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, uint4* ra, uint4* rb) {
     const int k = kt * BK + sc * 8;
     const bool kok = k < a.K;
     int tap, ci;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
       rb[i] = w;
     }
   };
-  auto store_tile = [&](int stage) {
+  auto store_tile = [&](int stage, const uint4* ra, const uint4* rb) {
     char* sa = smem + stage * STAGE_BYTES;
     char* sb = sa + TILE_BYTES;
 #pragma unroll
@@ -140,14 +140,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
     if (KFAST) { tap_u = (kt0 * BK) / Cin; ci_u = kt0 * BK - tap_u * Cin; }
   }
 
-  if (nk > 0) {
-  load_tile(kt0);
-  store_tile(0);
-  }
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tile(kt0 + kt + 1);
-    const char* sa = smem + (kt & 1) * STAGE_BYTES;
+  auto mma_tile = [&](int stage) {
+    const char* sa = smem + stage * STAGE_BYTES;
     const char* sb = sa + TILE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -162,8 +156,29 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = T::mfma32(wf[j], xf[i], acc[i][j]);
     }
-    if (kt + 1 < nk) store_tile((kt + 1) & 1);
+  };
+
+  // Pipeline: LDS holds k-tile t (stage t&1); tile t+1 sits in one register set (loaded during iteration t-1) and the loads
+  // of tile t+2 are issued into the other set before the MFMAs of tile t.  A 128x128x64 tile is only 16 MFMAs per wave --
+  // one tile of lookahead left every iteration waiting on its own global loads (measured ~3600 cycles per iteration pair
+  // against ~1500 for the LDS traffic).
+  if (nk > 0) {
+    load_tile(kt0, ra0, rb0);
+    if (nk > 1) load_tile(kt0 + 1, ra1, rb1);
+    store_tile(0, ra0, rb0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 2 < nk) load_tile(kt0 + kt + 2, ra0, rb0);
+    mma_tile(0);
+    if (kt + 1 < nk) store_tile(1, ra1, rb1);
     __syncthreads();
+    if (kt + 1 < nk) {
+      if (kt + 3 < nk) load_tile(kt0 + kt + 3, ra1, rb1);
+      mma_tile(1);
+      if (kt + 2 < nk) store_tile(0, ra0, rb0);
+      __syncthreads();
+    }
   }
 
   if (a.splitk > 1) {   // raw fp32 partial sums; bias / activation / residual happen in splitk_reduce_kernel

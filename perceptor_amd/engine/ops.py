@@ -28,6 +28,7 @@ def set_halo(enabled: bool) -> None:
 
 # bench.py sets this to a list to time every conv3x3_halo_kernel launch with HIP events on the launch stream
 KERNEL_EVENTS = None
+GEMM_TRACE = None    # tools/gemm_trace.py: list collecting (desc, flops, ev0, ev1) of every pmi_igemm launch
 DEBUG_WS = None      # tools/conv_probe.py --stamps: int64 buffer the PMI_STAMPS build of conv3x3.hip writes phase timestamps to
 
 
@@ -142,6 +143,16 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
                f"{' pro' if prologue is not None else ''}{' res' if residual is not None else ''}{' up' if up else ''}{' stats' if want_stats else ''}"
         KERNEL_EVENTS.append((e0, e1, 2.0 * m * lin.cout * lin.cin * lin.taps, float(nbytes), desc))
         return out
+    if GEMM_TRACE is not None:
+        kind = "conv" if conv and (lin.taps == 9 or up or stride == 2) else "gemm"
+        desc = f"{kind} M={m} N={lin.n_p} K={lin.K} taps={lin.taps}{' up' if up else ''}{' s2' if stride == 2 else ''} splitk={a.splitk}" \
+               f" halo={_hip.lib().pmi_conv3x3_halo_config(C.byref(a)) if HALO_ENABLED else -1}{' res' if residual is not None else ''}{' f32out' if a.out_f32 else ''}"
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call("pmi_igemm", C.byref(a))
+        e1.record()
+        GEMM_TRACE.append((desc, 2.0 * m * lin.n_p * lin.K, e0, e1))
+        return out
     call("pmi_igemm", C.byref(a))
     return out
 
@@ -163,6 +174,13 @@ def bgemm(A: torch.Tensor, B: torch.Tensor, D: torch.Tensor, *, M: int, N: int, 
     a.sB_o, a.sB_i = sB
     a.sD_o, a.sD_i = sD
     a.dtype = dt
+    if GEMM_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call("pmi_igemm", C.byref(a))
+        e1.record()
+        GEMM_TRACE.append((f"bgemm M={M} N={N} K={K} batch={batch}", 2.0 * M * N * K * batch, e0, e1))
+        return D
     call("pmi_igemm", C.byref(a))
     return D
 
