@@ -30,9 +30,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
+#ifdef PMI_STAMPS   // tools/gemm_probe.py --stamps: phase timestamps (100 MHz) per workgroup; a.reserved carries the enable flag
+#define GSTAMP(k) do { if (tid == 0 && a.reserved == 77 && a.splitk <= 1) ((long long*)a.ws)[(int64_t)blockIdx.x * 8 + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define GSTAMP(k) do {} while (0)
+#endif
+  GSTAMP(0);
   const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + BM - 1) / BM;
   const int logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int m0 = (logical / tiles_n) * BM, n0 = (logical % tiles_n) * BN;
+  // Each XCD (own L2) gets a contiguous range of tiles.  Row-major ranges re-read all of B per XCD, column-major ranges all
+  // of A: walk along the shorter operand so the longer one is split across the XCDs (ViT GEMMs: M = 2056, N up to 4096).
+  const bool nmajor = a.M < a.N;
+  const int m0 = (nmajor ? logical % tiles_m : logical / tiles_n) * BM, n0 = (nmajor ? logical / tiles_m : logical % tiles_n) * BN;
 
   const u16* A0 = (const u16*)a.A0;
   const u16* A1 = (const u16*)a.A1;
@@ -75,17 +84,54 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
   uint4 ra0[4], rb0[4], ra1[4], rb1[4];   // two register sets: global loads run two k-tiles ahead of the MFMAs
   int tap_u = 0, ci_u = 0;  // KFAST: uniform (tap, channel) of the next k-tile to load
 
+  // KFAST tiles are read with raw buffer loads (out-of-range offset = zero fill): no divergent branch around a load, so
+  // the compiler keeps exact vmcnt counts and the two-tile lookahead survives (see conv3x3.hip).  Bases are moved to the
+  // tile's first row / image so 32-bit offsets suffice.
+  const int hw_out = CONV ? a.H * a.W : 1;
+  const int img0 = CONV ? m0 / hw_out : 0;
+  const int64_t a_skip = CONV ? (int64_t)img0 * a.Hin * a.Win : (int64_t)m0;            // rows (pixels) in front of the base
+  const int64_t a_rows = (CONV ? (int64_t)(a.M / hw_out) * a.Hin * a.Win : (int64_t)a.M) - a_skip;
+  const u16* const A0b = A0 + a_skip * a.lda0;
+  const u16* const A1b = A1 ? A1 + a_skip * a.lda1 : A0b;
+  const int64_t bytesA0 = ((a_rows - 1) * a.lda0 + a.C0) * 2, bytesA1 = A1 ? ((a_rows - 1) * a.lda1 + a.C1) * 2 : 0;
+  const int nrows_b = min(BN, a.N - n0);
+  const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(Bw + (int64_t)n0 * a.ldb, ((int64_t)(nrows_b - 1) * a.ldb + a.K) * 2);
+  uint32_t vob[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) vob[i] = (uint32_t)((srow + 32 * i) * a.ldb + sc * 8) * 2u;
+
+  int kt_end = 0;                                        // first k-tile past this workgroup's range (set below)
   auto load_tile = [&](int kt, uint4* ra, uint4* rb) {
-    const int k = kt * BK + sc * 8;
-    const bool kok = k < a.K;
-    int tap, ci;
-    if (KFAST) {
-      tap = tap_u; ci = ci_u + sc * 8;
+    const bool dead = kt >= kt_end;                      // lookahead past the end: zero tiles, no control flow
+    if constexpr (KFAST) {
+      const int tap = tap_u, cbase = ci_u;
       ci_u += BK;
       if (ci_u >= Cin) { ci_u -= Cin; ++tap_u; }
-    } else {
-      tap = k / Cin; ci = k - tap * Cin;
+      const bool second = cbase >= a.C0;               // uniform: C0 is a multiple of BK
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(second ? A1b : A0b, second ? bytesA1 : bytesA0);
+      const uint32_t ld2 = (uint32_t)(second ? a.lda1 : a.lda0) * 2u;
+      const uint32_t so = (uint32_t)(cbase - (second ? a.C0 : 0)) * 2u;
+      int dy = 0, dx = 0;
+      if (CONV && a.taps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint32_t vo;
+        if (CONV) {
+          int iy = ys[i] + dy, ix = xs[i] + dx;
+          const bool ok = iy >= 0 && iy < Hv && ix >= 0 && ix < Wv;
+          if (a.up) { iy >>= 1; ix >>= 1; }
+          vo = ok && !dead ? (uint32_t)((nb[i] - img0 * a.Hin + iy) * a.Win + ix) * ld2 + (uint32_t)sc * 16u : PMI_BUF_OOB;
+        } else {
+          vo = dead ? PMI_BUF_OOB : (uint32_t)(srow + 32 * i) * ld2 + (uint32_t)sc * 16u;   // rows past M fall outside the resource
+        }
+        ra[i] = buf_load16(rs, vo, so);
+        rb[i] = buf_load16(rsrc_b, dead ? PMI_BUF_OOB : vob[i], (uint32_t)kt * (BK * 2));
+      }
+      return;
     }
+    const int k = kt * BK + sc * 8;
+    const bool kok = k < a.K && !dead;
+    const int tap = k / Cin, ci = k - tap * Cin;
     const bool second = ci >= a.C0;
     const u16* base = second ? A1 : A0;
     const int ld = second ? a.lda1 : a.lda0;
@@ -162,25 +208,28 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
   // of tile t+2 are issued into the other set before the MFMAs of tile t.  A 128x128x64 tile is only 16 MFMAs per wave --
   // one tile of lookahead left every iteration waiting on its own global loads (measured ~3600 cycles per iteration pair
   // against ~1500 for the LDS traffic).
-  if (nk > 0) {
-    load_tile(kt0, ra0, rb0);
-    if (nk > 1) load_tile(kt0 + 1, ra1, rb1);
-    store_tile(0, ra0, rb0);
-  }
+  kt_end = kt0 + nk;
+  load_tile(kt0, ra0, rb0);
+  load_tile(kt0 + 1, ra1, rb1);
+  store_tile(0, ra0, rb0);
   __syncthreads();
-  for (int kt = 0; kt < nk; kt += 2) {
-    if (kt + 2 < nk) load_tile(kt0 + kt + 2, ra0, rb0);
+  GSTAMP(1);
+  for (int kt = 0; kt < nk; kt += 2) {                   // an odd tile count runs one extra all-zero tile
+    load_tile(kt0 + kt + 2, ra0, rb0);
+    __builtin_amdgcn_sched_barrier(0);     // keep the loads in front of the MFMAs (the scheduler sinks them to their use)
     mma_tile(0);
-    if (kt + 1 < nk) store_tile(1, ra1, rb1);
+    __builtin_amdgcn_sched_barrier(0);
+    store_tile(1, ra1, rb1);
     __syncthreads();
-    if (kt + 1 < nk) {
-      if (kt + 3 < nk) load_tile(kt0 + kt + 3, ra1, rb1);
-      mma_tile(1);
-      if (kt + 2 < nk) store_tile(0, ra0, rb0);
-      __syncthreads();
-    }
+    load_tile(kt0 + kt + 3, ra1, rb1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_tile(1);
+    __builtin_amdgcn_sched_barrier(0);
+    store_tile(0, ra0, rb0);
+    __syncthreads();
   }
 
+  GSTAMP(2);
   if (a.splitk > 1) {   // raw fp32 partial sums; bias / activation / residual happen in splitk_reduce_kernel
     float* slab = (float*)a.ws + (int64_t)blockIdx.z * a.M * a.N;
 #pragma unroll
@@ -295,6 +344,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
     for (int c = tid; c < 2 * BN; c += 256)
       if (n0 + (c >> 1) < a.N) o[c] = stat[c];
   }
+#ifdef PMI_STAMPS
+  __syncthreads();
+  GSTAMP(3);
+#endif
 }
 
 // sum the split-K slabs and apply the fused epilogue (bias, per-sample bias, activation, residual), 4 channels per thread

@@ -130,6 +130,7 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
             out._pmi_stats = (st, rows)
     if DEBUG_WS is not None:
         a.ws = ptr(DEBUG_WS)
+        a.reserved = 77
     if KERNEL_EVENTS is not None and lin.taps == 9 and HALO_ENABLED and _hip.lib().pmi_conv3x3_halo_config(C.byref(a)) >= 0:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
