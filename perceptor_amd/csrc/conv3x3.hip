@@ -208,11 +208,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
   }
 
   STAMP(2);
-  // ---- epilogue: lane = pixel, registers = 4 consecutive output channels x 4 groups per 32x32 block ----
-  float* const stat = (float*)smem;            // [BN][2] per-channel (sum, sumsq) of this tile (LDS is free now)
+  // ---- epilogue ----
+  // Accumulator layout: lane = pixel, 4 consecutive channels per register group -- stored directly, a wave writes 32
+  // scattered 16-byte pieces per instruction and the address coalescer needs ~12-20 us per tile for it (in-kernel stamps).
+  // Instead each wave transposes its tile through LDS (free after the main loop), 64 channels at a time, and writes whole
+  // 128-byte lines: 16 bytes per lane, 8 pixels x 128 B per instruction.  The residual is read the same way.
+  constexpr int SROW = 144;                    // staged row: 64 channels x 2 B + 16 B pad (16-byte aligned, rows shift by 36 banks)
+  float* const stat = (float*)smem;            // [BN][2] per-channel (sum, sumsq) of this tile
   float* const bsm = stat + 2 * BN;            // [BN] bias + per-sample bias of the tile's channels
-  // The biases go through LDS: as per-lane global loads inside the store loop they cannot be hoisted above the preceding
-  // stores (may alias), which serialised 32 load->store round trips per wave (15 us of a 95 us tile, measured).
+  char* const stg = smem + 3 * BN * 4 + wid * (64 * SROW);
   for (int c = tid; c < BN; c += NT) {
     const int n = n0 + c;
     float b = 0.f;
@@ -225,62 +229,79 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
   if (a.stats)
     for (int c = tid; c < 2 * BN; c += NT) stat[c] = 0.f;
   __syncthreads();
-  int64_t mpix[XB], rrow[XB];
+  const int r8 = lane & 7, rp = lane >> 3;     // write-out role: 16-byte chunk (8 channels) r8 of pixel 8 t + rp
 #pragma unroll
-  for (int i = 0; i < XB; ++i) {
-    const int y = y0 + XB * wm + i, x = x0 + l31;
-    mpix[i] = ((int64_t)img * a.H + y) * a.W + x;
-    rrow[i] = mpix[i] * a.ldr;
-    if (a.R && a.res_up) rrow[i] = (((int64_t)img * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.ldr;
-  }
-  // The residual pieces of the wave's whole tile are fetched before the first store: interleaving each load with its
-  // store stretched the partial writes of a 128-byte output line over many load latencies, long enough for L2 to evict
-  // the line half-written (PMC WRITE_SIZE showed 2-4x the output bytes on the residual convs).  16-bit residual only.
-  uint2 rv[4][XB][4];
-  if (a.R) {
+  for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = pass * 2 + jj;
 #pragma unroll
       for (int i = 0; i < XB; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int n = n0 + wn * 128 + j * 32 + 4 * lhi + 8 * g;
-          rv[j][i][g] = make_uint2(0, 0);
-          if (n < a.N) rv[j][i][g] = *(const uint2*)((const u16*)a.R + rrow[i] + n);
+          const int cl = wn * 128 + j * 32 + 4 * lhi + 8 * g;
+          const float4 b = *(const float4*)(bsm + cl);
+          float v[4] = {acc[i][j][4 * g] * a.alpha + b.x, acc[i][j][4 * g + 1] * a.alpha + b.y,
+                        acc[i][j][4 * g + 2] * a.alpha + b.z, acc[i][j][4 * g + 3] * a.alpha + b.w};
+          if (a.act != PMI_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
+          }
+          *(uint2*)(stg + (i * 32 + l31) * SROW + (jj * 32 + 4 * lhi + 8 * g) * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
         }
-  }
+    }
+    const int cl0 = wn * 128 + pass * 64 + r8 * 8;           // this lane's 8 channels inside the tile
+    const bool nok = n0 + cl0 < a.N;
+    int64_t orow[8];
+    uint4 rres[8];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float ssum[16], ssq[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < XB; ++i) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * 128 + j * 32 + 4 * lhi + 8 * g;
-        if (n >= a.N) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * a.alpha;
-        { const float4 b = *(const float4*)(bsm + (n - n0)); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-        if (a.act != PMI_ACT_NONE) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
-        }
-        if (a.R) {
-          const uint2 r = rv[j][i][g];
-          v[0] += T::to_f((u16)(r.x & 0xffff)); v[1] += T::to_f((u16)(r.x >> 16));
-          v[2] += T::to_f((u16)(r.y & 0xffff)); v[3] += T::to_f((u16)(r.y >> 16));
-        }
-        const int64_t o = mpix[i] * a.ldd + n;
-        if (a.out_f32) *(float4*)((float*)a.D + o) = make_float4(v[0], v[1], v[2], v[3]);
-        else *(uint2*)((u16*)a.D + o) = pack4<T>(v[0], v[1], v[2], v[3]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { ssum[4 * g + e] += v[e]; ssq[4 * g + e] += v[e] * v[e]; }
+    for (int t = 0; t < 8; ++t) {
+      const int p = 8 * t + rp;
+      const int y = y0 + XB * wm + (p >> 5), x = x0 + (p & 31);
+      orow[t] = (((int64_t)img * a.H + y) * a.W + x) * a.ldd + n0 + cl0;
+      rres[t] = make_uint4(0, 0, 0, 0);
+      if (a.R && nok) {
+        const int64_t rr = a.res_up ? (((int64_t)img * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.ldr
+                                    : (((int64_t)img * a.H + y) * a.W + x) * a.ldr;
+        rres[t] = *(const uint4*)((const u16*)a.R + rr + n0 + cl0);
       }
     }
-    if (a.stats) stats_block_to_lds(ssum, ssq, stat, wn * 128 + j * 32, lane);
+    float cs[16];                                           // [0..7] sums, [8..15] sums of squares of the lane's channels
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cs[e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      uint4 v = *(const uint4*)(stg + (8 * t + rp) * SROW + r8 * 16);
+      if (a.R || a.stats) {
+        float f[8];
+        unpack8<T>(v, f);
+        if (a.R) {
+          float r[8];
+          unpack8<T>(rres[t], r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += r[e];
+          v = pack8<T>(f);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { cs[e] += f[e]; cs[8 + e] += f[e] * f[e]; }
+      }
+      if (nok) *(uint4*)((u16*)a.D + orow[t]) = v;
+    }
+    if (a.stats) {
+      // butterfly over the 8 lanes that share r8 (lane bits 3..5), halving the live values per step: 14 shuffles
+      float b8[8], b4[4], b2[2];
+      const bool h3 = lane & 8, h4 = lane & 16, h5 = lane & 32;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float mine = h3 ? cs[k + 8] : cs[k], other = h3 ? cs[k] : cs[k + 8]; b8[k] = mine + __shfl_xor(other, 8); }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float mine = h4 ? b8[k + 4] : b8[k], other = h4 ? b8[k] : b8[k + 4]; b4[k] = mine + __shfl_xor(other, 16); }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) { const float mine = h5 ? b4[k + 2] : b4[k], other = h5 ? b4[k] : b4[k + 2]; b2[k] = mine + __shfl_xor(other, 32); }
+      // the lane now holds the totals of value index h3 * 8 + h4 * 4 + h5 * 2 + k: statistic h3 of channel h4 * 4 + h5 * 2 + k
+      const int e0 = (h4 ? 4 : 0) + (h5 ? 2 : 0);
+      atomicAdd(&stat[2 * (cl0 + e0) + (h3 ? 1 : 0)], b2[0]);
+      atomicAdd(&stat[2 * (cl0 + e0 + 1) + (h3 ? 1 : 0)], b2[1]);
+    }
   }
   STAMP(3);
   if (a.stats) {
@@ -339,7 +360,7 @@ void pmi_conv3x3_persistent(int) {}    // incremental patch staging: measured (8
 // Returns the tile config the halo kernel runs for this shape (0: 8x32 px x 256 ch / 8 waves, 1: 16x32 x 128 / 8 waves,
 // 2: 8x32 x 128 / 4 waves x 2 workgroups per CU) or -1 if the shape needs the generic kernel.
 extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
-  if (a->taps != 9 || a->stride != 1 || a->batch > 1 || (a->R && a->res_f32)) return -1;
+  if (a->taps != 9 || a->stride != 1 || a->batch > 1 || (a->R && a->res_f32) || a->out_f32) return -1;
   const int Cin = a->C0 + a->C1;
   if ((Cin % 64) || (a->C0 % 64) || (a->W % 32) || (a->H % 8) || (a->N % 128)) return -1;
   const bool ok0 = (a->N % 256) == 0 || a->N >= 256, ok1 = (a->H % 16) == 0;
