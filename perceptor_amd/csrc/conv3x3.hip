@@ -29,13 +29,14 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((ch
 // hardware returns zeros): no divergent branch around a load.  With `if (inside) v = load` the compiler lost count of the
 // loads in flight at every branch join and fell back to s_waitcnt vmcnt(0) -- right after issuing the next tap's weight
 // loads, i.e. one exposed L2 round trip per tap in front of the MFMAs.
-template <typename T, int WM, int WN, int PRO, bool EARLY>
+// NJ: 32-channel MFMA blocks per wave (4 = 128 output channels; 1 for convs with <= 32 output channels, e.g. the UNet's last conv).
+template <typename T, int WM, int WN, int PRO, bool EARLY, int NJ = 4>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi_igemm_args a) {
   constexpr int XB = 2;                                // image rows (32-pixel MFMA blocks) per wave
   constexpr int TH = WM * XB;                          // image rows per tile
   constexpr int NT = WM * WN * 64;                     // threads per workgroup
   constexpr int RPI = NT / 8;                          // tile rows staged per pass (8 threads x 16 B per 128-B row)
-  constexpr int BN = WN * 128;
+  constexpr int BN = WN * NJ * 32;
   constexpr int PP = (TH + 2) * PW;                    // patch pixels
   constexpr int NPI = (PP + RPI - 1) / RPI;            // 16-byte patch chunks per thread
   constexpr int NWI = BN / RPI;                        // 16-byte weight chunks per thread per tap
@@ -142,11 +143,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
     for (int i = 0; i < NWI; ++i) *(uint4*)(wb + swz((tid >> 3) + RPI * i, sc)) = wr[i];
   };
 
-  f32x16 acc[XB][4];
+  f32x16 acc[XB][NJ];
 #pragma unroll
   for (int i = 0; i < XB; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -156,15 +157,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int ch = kk * 2 + lhi;
-      uint4 xf[XB], wf[4];
+      uint4 xf[XB], wf[NJ];
 #pragma unroll
       for (int i = 0; i < XB; ++i) xf[i] = *(const uint4*)(smem + swz((XB * wm + i + dy) * PW + l31 + dx, ch));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wf[j] = *(const uint4*)(wb + swz(wn * 128 + j * 32 + l31, ch));
+      for (int j = 0; j < NJ; ++j) wf[j] = *(const uint4*)(wb + swz(wn * NJ * 32 + j * 32 + l31, ch));
 #pragma unroll
       for (int i = 0; i < XB; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma32(wf[j], xf[i], acc[i][j]);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma32(wf[j], xf[i], acc[i][j]);
     }
   };
 
@@ -208,6 +209,34 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
   }
 
   STAMP(2);
+  if constexpr (NJ < 4) {
+    // ---- epilogue, few output channels (N <= 32): 4 channels per lane straight from the accumulator layout; with ldd = 8 the
+    // 32 pixels of a wave row form one contiguous 1 KB run.  No residual / statistics on this path.
+    STAMP(2);
+#pragma unroll
+    for (int i = 0; i < XB; ++i) {
+      const int y = y0 + XB * wm + i, x = x0 + l31;
+      const int64_t o = (((int64_t)img * a.H + y) * a.W + x) * a.ldd;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n0 + wn * NJ * 32 + j * 32 + 4 * lhi + 8 * g;
+          if (n >= a.N) continue;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = acc[i][j][4 * g + e] * a.alpha;
+            if (a.bias) v[e] += a.bias[n + e];
+            if (a.nbias) v[e] += a.nbias[(int64_t)img * (a.ldnb ? a.ldnb : a.N) + n + e];
+            if (a.act != PMI_ACT_NONE) v[e] = act_apply(v[e], a.act);
+          }
+          if (a.out_f32) *(float4*)((float*)a.D + o + n) = make_float4(v[0], v[1], v[2], v[3]);
+          else *(uint2*)((u16*)a.D + o + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+        }
+    }
+    return;
+  } else {
   // ---- epilogue ----
   // Accumulator layout: lane = pixel, 4 consecutive channels per register group -- stored directly, a wave writes 32
   // scattered 16-byte pieces per instruction and the address coalescer needs ~12-20 us per tile for it (in-kernel stamps).
@@ -310,6 +339,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
     for (int c = tid; c < 2 * BN; c += NT)
       if (n0 + (c >> 1) < a.N) o[c] = stat[c];
   }
+  }
 #ifdef PMI_STAMPS
   __syncthreads();
   if (tid == 0 && a.ws) {
@@ -330,6 +360,9 @@ int launch_p(const pmi_igemm_args& a, hipStream_t s, int cfg) {
   } else if (cfg == 1) {   // 16x32 px x 128 ch, 8 waves
     const int tiles = nimg * (a.H / 16) * (a.W / 32) * ((a.N + 127) / 128);
     hipLaunchKernelGGL((conv3x3_halo_kernel<T, 8, 1, PRO, PRO == 0>), dim3(tiles), dim3(512), 0, s, a);
+  } else if (cfg == 3) {   // 8x32 px x 32 ch, 4 waves: convs with a handful of output channels (memory-bound on the input)
+    const int tiles = nimg * (a.H / 8) * (a.W / 32) * ((a.N + 31) / 32);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, 4, 1, PRO, false, 1>), dim3(tiles), dim3(256), 0, s, a);
   } else {                 // 8x32 px x 128 ch, 4 waves, two workgroups per CU overlap each other's staging / epilogue
     const int tiles = nimg * (a.H / 8) * (a.W / 32) * ((a.N + 127) / 128);
     hipLaunchKernelGGL((conv3x3_halo_kernel<T, 4, 1, PRO, false>), dim3(tiles), dim3(256), 0, s, a);
@@ -358,11 +391,14 @@ void pmi_conv3x3_use_glds(int) {}      // experiments measured and dropped (DESI
 void pmi_conv3x3_persistent(int) {}    // incremental patch staging: measured (876 vs 943 TFLOP/s) and dropped
 
 // Returns the tile config the halo kernel runs for this shape (0: 8x32 px x 256 ch / 8 waves, 1: 16x32 x 128 / 8 waves,
-// 2: 8x32 x 128 / 4 waves x 2 workgroups per CU) or -1 if the shape needs the generic kernel.
+// 2: 8x32 x 128 / 4 waves x 2 workgroups per CU, 3: 8x32 px x <= 32 channels) or -1 if the shape needs the generic kernel.
 extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
-  if (a->taps != 9 || a->stride != 1 || a->batch > 1 || (a->R && a->res_f32) || a->out_f32) return -1;
+  if (a->taps != 9 || a->stride != 1 || a->batch > 1 || (a->R && a->res_f32)) return -1;
   const int Cin = a->C0 + a->C1;
-  if ((Cin % 64) || (a->C0 % 64) || (a->W % 32) || (a->H % 8) || (a->N % 128)) return -1;
+  if ((Cin % 64) || (a->C0 % 64) || (a->W % 32) || (a->H % 8)) return -1;
+  // config 3: at most 32 output channels (the UNet's last conv, 128 -> 6): one MFMA block column per wave
+  if (a->N <= 32 && (a->N % 4) == 0 && !a->R && !a->stats && !a->res_up && a->M / (a->H * a->W) * (a->H / 8) * (a->W / 32) >= 256) return 3;
+  if ((a->N % 128) || a->out_f32) return -1;
   const bool ok0 = (a->N % 256) == 0 || a->N >= 256, ok1 = (a->H % 16) == 0;
   if (g_force_cfg == 0 && ok0) return 0;
   if (g_force_cfg == 1 && ok1) return 1;

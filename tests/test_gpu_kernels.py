@@ -56,6 +56,8 @@ def _check(got, ref, dtype, extra=1.0):
     dict(n=2, h=8, w=32, cin=64, cout=256, k=3, prologue=True, force_cfg=0),
     dict(n=2, h=8, w=32, cin=128, cout=128, k=3, prologue=True, force_cfg=2),
     dict(n=8, h=64, w=64, cin=64, cout=256, k=3, prologue=True),           # enough tiles for the halo kernel by itself
+    dict(n=8, h=128, w=64, cin=64, cout=6, k=3, f32=True, prologue=True),  # last conv of the UNet: halo config 3 (<= 32 output channels), fp32 out
+    dict(n=8, h=128, w=64, cin=128, cout=24, k=3),                         # config 3, 16-bit out (no residual on this path)
     dict(n=2, h=16, w=16, cin=512, cout=128, k=3),                        # few tiles, long K: split-K slabs + reduce
     dict(n=1, h=8, w=8, cin=1024, cout=256, k=3, res_up=False),
 ])
@@ -93,12 +95,15 @@ def test_igemm_conv(case, dtype):
     a0, a1 = xs, None
     if "split" in case:
         a0, a1 = xs[..., :case["split"]].contiguous(), xs[..., case["split"]:].contiguous()
-    out = ops.igemm(a0, lin, a1=a1, prologue=pro, residual=_nhwc(res_in, dtype).to(dev) if not case.get("f32") else None,
+    out = ops.igemm(a0, lin, a1=a1, prologue=pro, residual=_nhwc(res_in, dtype).to(dev) if not case.get("f32") else None,   # (the residual case keeps cout=24 on the generic kernel)
                     act=1, up=up, stride=stride, res_up=case.get("res_up", False), out_f32=case.get("f32", False))
     if case.get("f32"):
         ref = ref - res
         got = out[..., :cout].permute(0, 3, 1, 2).cpu()
-        assert float((got - ref).abs().max()) <= 2e-5 * (float(ref.abs().max()) + 1)
+        # with the fused prologue a few activations round to the neighbouring 16-bit value (fast exp/rcp in the kernel vs torch's silu):
+        # tolerance is then a fraction of an input ulp instead of fp32 summation noise
+        tol = (0.25 * ULP[dtype] if case.get("prologue") else 2e-5) * (float(ref.abs().max()) + 1)
+        assert float((got - ref).abs().max()) <= tol
     else:
         _check(out[..., :cout].permute(0, 3, 1, 2).cpu(), ref, dtype)
     _hip.lib().pmi_set_option(1, -1)
