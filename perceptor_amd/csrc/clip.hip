@@ -56,6 +56,35 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   const float* xr = x + row * D;
   const float mean = mean_i[r], rstd = rstd_i[r];
   float s1 = 0.f, s2 = 0.f;
+  if ((D & 255) == 0 && D <= 2048 && (dy_ld & 3) == 0) {
+    // one pass over HBM: 16-byte loads, the row (gy, xhat) stays in registers between the reduction and the write-out
+    float4 gy[8], xh[8];
+    const int nv = D >> 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < nv) {
+        const int c = (lane + 64 * k) * 4;
+        const float4 d = *(const float4*)(dyr + c), g = *(const float4*)(gamma + c), xv = *(const float4*)(xr + c);
+        gy[k] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+        xh[k] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        s1 += gy[k].x + gy[k].y + gy[k].z + gy[k].w;
+        s2 += gy[k].x * xh[k].x + gy[k].y * xh[k].y + gy[k].z * xh[k].z + gy[k].w * xh[k].w;
+      }
+    }
+    s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < nv) {
+        const int c = (lane + 64 * k) * 4;
+        float4 v = make_float4(rstd * (gy[k].x - s1 - xh[k].x * s2), rstd * (gy[k].y - s1 - xh[k].y * s2),
+                               rstd * (gy[k].z - s1 - xh[k].z * s2), rstd * (gy[k].w - s1 - xh[k].w * s2));
+        if (gres) { const float4 gr = *(const float4*)(gres + row * D + c); v.x += gr.x; v.y += gr.y; v.z += gr.z; v.w += gr.w; }
+        if (g32) *(float4*)(g32 + row * D + c) = v;
+        if (g16) *(uint2*)(g16 + row * D + c) = pack4<T>(v.x, v.y, v.z, v.w);
+      }
+    }
+    return;
+  }
   for (int c = lane; c < D; c += 64) {
     const float gy = dyr[c] * gamma[c], xh = (xr[c] - mean) * rstd;
     s1 += gy; s2 += gy * xh;

@@ -56,12 +56,32 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, n = blockIdx.x, g = blockIdx.y;
   const int C = C0 + C1, cpg = C / G;
   double s = 0.0, q = 0.0;
-  for (int j = 0; j < cpg; ++j) {
-    const int c = g * cpg + j;
-    const bool second = c >= C0;
-    const float* src = second ? s1 + ((int64_t)n * P1 * C1 + (c - C0)) * 2 : s0 + ((int64_t)n * P0 * C0 + c) * 2;
-    const int P = second ? P1 : P0, ld = (second ? C1 : C0) * 2;
-    for (int p = tid; p < P; p += 256) { s += src[(int64_t)p * ld]; q += src[(int64_t)p * ld + 1]; }
+  if (cpg <= 256) {
+    // thread = (partial row, channel of the group): the group's cpg (sum, sumsq) pairs of a row are contiguous, so a wave
+    // reads whole 8*cpg-byte runs instead of one strided pair per thread
+    const int j = tid % cpg, plane = tid / cpg, pstep = 256 / cpg;
+    if (plane < pstep) {
+      const int c = g * cpg + j;
+      const bool second = c >= C0;
+      const float* src = second ? s1 + ((int64_t)n * P1 * C1 + (c - C0)) * 2 : s0 + ((int64_t)n * P0 * C0 + c) * 2;
+      const int P = second ? P1 : P0, ld = (second ? C1 : C0) * 2;
+      float fs = 0.f, fq = 0.f;
+      int cnt = 0;
+      for (int p = plane; p < P; p += pstep) {
+        const float2 v = *(const float2*)(src + (int64_t)p * ld);
+        fs += v.x; fq += v.y;
+        if (++cnt == 64) { s += fs; q += fq; fs = fq = 0.f; cnt = 0; }   // short fp32 runs, double across them
+      }
+      s += fs; q += fq;
+    }
+  } else {
+    for (int j = 0; j < cpg; ++j) {
+      const int c = g * cpg + j;
+      const bool second = c >= C0;
+      const float* src = second ? s1 + ((int64_t)n * P1 * C1 + (c - C0)) * 2 : s0 + ((int64_t)n * P0 * C0 + c) * 2;
+      const int P = second ? P1 : P0, ld = (second ? C1 : C0) * 2;
+      for (int p = tid; p < P; p += 256) { s += src[(int64_t)p * ld]; q += src[(int64_t)p * ld + 1]; }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
