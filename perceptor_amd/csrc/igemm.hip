@@ -435,7 +435,7 @@ extern "C" int pmi_igemm_splitk(const pmi_igemm_args* a) {
   if (g_allow_halo && pmi_conv3x3_halo_config(a) >= 0) return 1;
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
   const int nk = (a->K + BK - 1) / BK;
-  if (tiles >= 192 || nk < 16) return 1;
+  if (tiles >= 384 || nk < 16) return 1;     // 2 workgroups fit per CU: below 384 tiles part of the chip idles through a long K loop
   int s = 512 / tiles;
   if (s > nk / 8) s = nk / 8;
   if (s > 16) s = 16;
