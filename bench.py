@@ -46,8 +46,8 @@ CONFIGS = {
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=10)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--config", default="c5", choices=sorted(CONFIGS))
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     p.add_argument("--no-cpu-baseline", action="store_true")
