@@ -111,16 +111,20 @@ class VelocityDiffusion(torch.nn.Module):
     def velocities(self, diffused, t, conditioning=None):
         eng = self._need_engine()
         diffused = diffused.to(self.device)
-        if isinstance(t, float) or t.ndim == 0:
+        if isinstance(t, float):
             t = torch.full((diffused.shape[0],), float(t))
+        elif t.ndim == 0:          # same value as the reference's float(t), without a device->host sync (HIP-graph capturable)
+            t = t.reshape(1).expand(diffused.shape[0])
         ce = conditioning.squeeze(dim=1) if (self.spec["cond"] and conditioning is not None) else None
         if self.spec["cond"] and ce is not None and ce.shape[0] == 1 and diffused.shape[0] > 1:
             ce = ce.expand(diffused.shape[0], -1)
         return eng.forward(diffused, t, ce)
 
     def forward(self, diffused_images, ts, conditioning=None) -> Predictions:
-        if isinstance(ts, float) or ts.ndim == 0:
+        if isinstance(ts, float):
             ts = torch.full((diffused_images.shape[0],), float(ts)).to(diffused_images)
+        elif ts.ndim == 0:
+            ts = ts.reshape(1).expand(diffused_images.shape[0]).to(diffused_images)
         return Predictions(from_diffused_images=diffused_images, from_ts=ts,
                            velocities=self.velocities(diffused_images, ts, conditioning))
 
