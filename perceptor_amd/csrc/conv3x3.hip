@@ -211,7 +211,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
   STAMP(2);
   if constexpr (NJ < 4) {
     // ---- epilogue, few output channels (N <= 32): 4 channels per lane straight from the accumulator layout; with ldd = 8 the
-    // 32 pixels of a wave row form one contiguous 1 KB run.  No residual / statistics on this path.
+    // 32 pixels of a wave row form one contiguous 1 KB run.  No statistics / nearest-up residual on this path.
     STAMP(2);
 #pragma unroll
     for (int i = 0; i < XB; ++i) {
@@ -230,6 +230,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
             if (a.bias) v[e] += a.bias[n + e];
             if (a.nbias) v[e] += a.nbias[(int64_t)img * (a.ldnb ? a.ldnb : a.N) + n + e];
             if (a.act != PMI_ACT_NONE) v[e] = act_apply(v[e], a.act);
+          }
+          if (a.R) {
+            const int64_t ro = (((int64_t)img * a.H + y) * a.W + x) * a.ldr + n;
+            if (a.res_f32) {
+              const float4 r = *(const float4*)((const float*)a.R + ro);
+              v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+            } else {
+              const uint2 r = *(const uint2*)((const u16*)a.R + ro);
+              v[0] += T::to_f((u16)(r.x & 0xffff)); v[1] += T::to_f((u16)(r.x >> 16));
+              v[2] += T::to_f((u16)(r.y & 0xffff)); v[3] += T::to_f((u16)(r.y >> 16));
+            }
           }
           if (a.out_f32) *(float4*)((float*)a.D + o + n) = make_float4(v[0], v[1], v[2], v[3]);
           else *(uint2*)((u16*)a.D + o + n) = pack4<T>(v[0], v[1], v[2], v[3]);
@@ -393,12 +404,12 @@ void pmi_conv3x3_persistent(int) {}    // incremental patch staging: measured (8
 // Returns the tile config the halo kernel runs for this shape (0: 8x32 px x 256 ch / 8 waves, 1: 16x32 x 128 / 8 waves,
 // 2: 8x32 x 128 / 4 waves x 2 workgroups per CU, 3: 8x32 px x <= 32 channels) or -1 if the shape needs the generic kernel.
 extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
-  if (a->taps != 9 || a->stride != 1 || a->batch > 1 || (a->R && a->res_f32)) return -1;
+  if (a->taps != 9 || a->stride != 1 || a->batch > 1) return -1;
   const int Cin = a->C0 + a->C1;
   if ((Cin % 64) || (a->C0 % 64) || (a->W % 32) || (a->H % 8)) return -1;
   // config 3: at most 32 output channels (the UNet's last conv, 128 -> 6): one MFMA block column per wave
-  if (a->N <= 32 && (a->N % 4) == 0 && !a->R && !a->stats && !a->res_up && a->M / (a->H * a->W) * (a->H / 8) * (a->W / 32) >= 256) return 3;
-  if ((a->N % 128) || a->out_f32) return -1;
+  if (a->N <= 32 && (a->N % 4) == 0 && !a->stats && !a->res_up && a->M / (a->H * a->W) * (a->H / 8) * (a->W / 32) >= 256) return 3;
+  if ((a->N % 128) || a->out_f32 || (a->R && a->res_f32)) return -1;
   const bool ok0 = (a->N % 256) == 0 || a->N >= 256, ok1 = (a->H % 16) == 0;
   if (g_force_cfg == 0 && ok0) return 0;
   if (g_force_cfg == 1 && ok1) return 1;
