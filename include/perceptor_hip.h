@@ -76,7 +76,8 @@ int pmi_igemm_splitk(const pmi_igemm_args* a);
 /* number of per-image partial rows the fused output statistics of this call would produce (0: not available for this shape) */
 int pmi_igemm_stats_rows(const pmi_igemm_args* a);
 /* debugging / A-B switches: key 0 = allow the LDS-halo conv3x3 kernel (default 1, returns the previous value);
- * key 1 = force halo tile config 0/1/2 where eligible (-1 = automatic). */
+ * key 1 = force halo tile config 0/1/2 where eligible (-1 = automatic);
+ * key 4 = route plain GEMMs (one source, no convolution gather, no fused activation / statistics) to hipBLASLt (default 1). */
 int pmi_set_option(int key, int value);
 
 /* ---- GroupNorm (+FiLM, +activation, +2x2 average pool) ---------------------------

@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libperceptor_hip.so")
-SOURCES = ["igemm.hip", "conv3x3.hip", "norm.hip", "attn.hip", "elementwise.hip", "clip.hip"]
+SOURCES = ["igemm.hip", "conv3x3.hip", "norm.hip", "attn.hip", "elementwise.hip", "clip.hip", "gemm_lt.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 
 
@@ -35,10 +35,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
             subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+    with ThreadPoolExecutor(max_workers=min(7, len(srcs))) as ex:
         objs = list(ex.map(compile_one, srcs))
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lhipblaslt"]   # hipBLASLt: plain library GEMMs only
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -1,0 +1,100 @@
+// Plain GEMMs (no convolution gather, one source, no per-sample bias / statistics / activation) through hipBLASLt.
+// The ViT linears at M = 8 x 257 rows and the single-source 1x1 convolutions are plain library GEMMs; the vendor library's
+// tuned macro-tiles run them 1.4-1.9x faster than the generic 128x128 implicit-GEMM kernel (2056 x 4096 x 1024: 23 vs 43 us),
+// which stays the fallback for every shape the heuristic does not serve.  Hand-written kernels keep everything that is fused.
+//
+//   D[m][n] = alpha * sum_k A[m][k] * B[n][k] + bias[n] + R[m][n]      (row-major, 16-bit A/B, 16-bit or fp32 D/R)
+// In the library's column-major terms: D'(N x M) = op_T(B')(N x K) * A'(K x M), bias along the rows of D'.
+#include <hipblaslt/hipblaslt.h>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include "common.h"
+#include "../../include/perceptor_hip.h"
+
+namespace {
+
+struct Plan {
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr, ld = nullptr;
+  hipblasLtMatmulHeuristicResult_t heur;
+  bool ok = false;
+};
+
+using Key = std::tuple<int, int, int, int, int, int, int, int, int, int, int>;
+std::map<Key, Plan> g_plans;
+std::mutex g_mu;
+hipblasLtHandle_t g_handle = nullptr;
+void* g_ws = nullptr;
+constexpr size_t WS_BYTES = 64u << 20;
+int g_enabled = 1;
+
+bool eligible(const pmi_igemm_args& a) {
+  if (!g_enabled) return false;
+  if (a.taps != 1 || a.up || a.stride != 1 || a.batch > 1 || a.C1 != 0 || a.A1) return false;
+  if (a.nbias || a.stats || a.pro_a || a.act != PMI_ACT_NONE || a.splitk > 1 || a.res_up) return false;
+  if (a.R && (a.res_f32 != 0) != (a.out_f32 != 0)) return false;
+  if (a.M < 256 || (a.K & 7) || a.K != a.C0) return false;
+  return true;
+}
+
+Plan& plan_for(const pmi_igemm_args& a) {
+  const Key key{a.M, a.N, a.K, a.lda0, a.ldb, a.ldd, a.R ? a.ldr : -1, a.dtype, a.out_f32, a.bias ? 1 : 0, 0};
+  auto it = g_plans.find(key);
+  if (it != g_plans.end()) return it->second;
+  Plan p;
+  const hipDataType in_t = a.dtype == PMI_DT_BF16 ? HIP_R_16BF : HIP_R_16F;
+  const hipDataType out_t = a.out_f32 ? HIP_R_32F : in_t;
+  bool good = hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS;
+  const hipblasOperation_t opT = HIPBLAS_OP_T, opN = HIPBLAS_OP_N;
+  good = good && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opT, sizeof(opT)) == HIPBLAS_STATUS_SUCCESS;
+  good = good && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opN, sizeof(opN)) == HIPBLAS_STATUS_SUCCESS;
+  if (good && a.bias) {
+    const hipblasLtEpilogue_t ep = HIPBLASLT_EPILOGUE_BIAS;
+    const hipDataType bt = HIP_R_32F;
+    good = good && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &ep, sizeof(ep)) == HIPBLAS_STATUS_SUCCESS;
+    good = good && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt)) == HIPBLAS_STATUS_SUCCESS;
+  }
+  good = good && hipblasLtMatrixLayoutCreate(&p.la, in_t, a.K, a.N, a.ldb) == HIPBLAS_STATUS_SUCCESS;    // weights, K x N col-major
+  good = good && hipblasLtMatrixLayoutCreate(&p.lb, in_t, a.K, a.M, a.lda0) == HIPBLAS_STATUS_SUCCESS;   // activations, K x M
+  good = good && hipblasLtMatrixLayoutCreate(&p.lc, out_t, a.N, a.M, a.R ? a.ldr : a.ldd) == HIPBLAS_STATUS_SUCCESS;
+  good = good && hipblasLtMatrixLayoutCreate(&p.ld, out_t, a.N, a.M, a.ldd) == HIPBLAS_STATUS_SUCCESS;
+  if (good) {
+    hipblasLtMatmulPreference_t pref = nullptr;
+    good = hipblasLtMatmulPreferenceCreate(&pref) == HIPBLAS_STATUS_SUCCESS;
+    size_t ws = WS_BYTES;
+    good = good && hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws, sizeof(ws)) == HIPBLAS_STATUS_SUCCESS;
+    int found = 0;
+    good = good && hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.la, p.lb, p.lc, p.ld, pref, 1, &p.heur, &found) == HIPBLAS_STATUS_SUCCESS;
+    good = good && found > 0;
+    if (pref) hipblasLtMatmulPreferenceDestroy(pref);
+  }
+  p.ok = good;
+  return g_plans.emplace(key, p).first->second;
+}
+
+}  // namespace
+
+void pmi_gemm_lt_enable(int v) { g_enabled = v; }
+int pmi_gemm_lt_eligible(const pmi_igemm_args* a) { return eligible(*a) ? 1 : 0; }
+
+// PMI_OK when the library ran the GEMM, 1 when the caller should use the generic kernel instead
+int pmi_gemm_lt(const pmi_igemm_args* a, void* stream) {
+  if (!eligible(*a)) return 1;
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (!g_handle) {
+    if (hipblasLtCreate(&g_handle) != HIPBLAS_STATUS_SUCCESS) { g_handle = nullptr; g_enabled = 0; return 1; }
+    if (hipMalloc(&g_ws, WS_BYTES) != hipSuccess) { g_ws = nullptr; g_enabled = 0; return 1; }
+  }
+  Plan& p = plan_for(*a);
+  if (!p.ok) return 1;
+  if (a->bias) {
+    const void* bp = a->bias;
+    if (hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bp, sizeof(bp)) != HIPBLAS_STATUS_SUCCESS) return 1;
+  }
+  const float alpha = a->alpha, beta = a->R ? 1.f : 0.f;
+  const void* C = a->R ? a->R : a->D;
+  const hipblasStatus_t st = hipblasLtMatmul(g_handle, p.desc, &alpha, a->B, p.la, a->A0, p.lb, &beta, C, p.lc, a->D, p.ld, &p.heur.algo,
+                                             g_ws, WS_BYTES, (hipStream_t)stream);
+  return st == HIPBLAS_STATUS_SUCCESS ? PMI_OK : 1;
+}

@@ -424,6 +424,9 @@ int launch(const pmi_igemm_args& a, hipStream_t s) {
 
 extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a);
 int pmi_conv3x3_halo_launch(const pmi_igemm_args* a, int cfg, void* stream);
+int pmi_gemm_lt(const pmi_igemm_args* a, void* stream);          // gemm_lt.hip: 0 = done by hipBLASLt, 1 = use the generic kernel
+int pmi_gemm_lt_eligible(const pmi_igemm_args* a);
+void pmi_gemm_lt_enable(int v);
 void pmi_conv3x3_force_config(int cfg);
 void pmi_conv3x3_use_glds(int v);
 void pmi_conv3x3_persistent(int v);
@@ -433,6 +436,7 @@ static int g_allow_halo = 1;
 extern "C" int pmi_igemm_splitk(const pmi_igemm_args* a) {
   if (a->batch > 1 || (a->N & 3)) return 1;
   if (g_allow_halo && pmi_conv3x3_halo_config(a) >= 0) return 1;
+  if (pmi_gemm_lt_eligible(a)) return 1;                        // plain GEMM: the library balances its own tiles
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
   const int nk = (a->K + BK - 1) / BK;
   if (tiles >= 384 || nk < 16) return 1;     // 2 workgroups fit per CU: below 384 tiles part of the chip idles through a long K loop
@@ -456,6 +460,7 @@ extern "C" int pmi_set_option(int key, int value) {
   if (key == 1) { pmi_conv3x3_force_config(value); return 0; }
   if (key == 2) { pmi_conv3x3_use_glds(value); return 0; }
   if (key == 3) { pmi_conv3x3_persistent(value); return 0; }
+  if (key == 4) { pmi_gemm_lt_enable(value); return 0; }
   return PMI_ERR_ARG;
 }
 
@@ -482,6 +487,7 @@ extern "C" int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream) {
   if (a->stats && a->stats_p != pmi_igemm_stats_rows(a)) return PMI_ERR_ARG;
   if (a->splitk > 1 && (!a->ws || a->batch > 1 || halo >= 0 || (a->N & 3) || a->stats)) return PMI_ERR_ARG;
   if (halo >= 0) return pmi_conv3x3_halo_launch(a, halo, stream);
+  if (pmi_gemm_lt(a, stream) == PMI_OK) return PMI_OK;           // plain GEMMs go to hipBLASLt when it has a kernel for the shape
   hipStream_t s = (hipStream_t)stream;
   return a->dtype == PMI_DT_BF16 ? launch<BF16>(*a, s) : launch<F16>(*a, s);
 }
