@@ -14,11 +14,13 @@
 
 namespace {
 
+constexpr int MAX_ALGOS = 8;
 struct Plan {
   hipblasLtMatmulDesc_t desc = nullptr;
   hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr, ld = nullptr;
-  hipblasLtMatmulHeuristicResult_t heur;
-  bool ok = false;
+  hipblasLtMatmulHeuristicResult_t heur[MAX_ALGOS];
+  int nalgo = 0, best = 0;
+  bool tuned = false, ok = false;
 };
 
 using Key = std::tuple<int, int, int, int, int, int, int, int, int, int, int>;
@@ -27,7 +29,7 @@ std::mutex g_mu;
 hipblasLtHandle_t g_handle = nullptr;
 void* g_ws = nullptr;
 constexpr size_t WS_BYTES = 64u << 20;
-int g_enabled = 1;
+int g_enabled = 1, g_tune = 1;
 
 bool eligible(const pmi_igemm_args& a) {
   if (!g_enabled) return false;
@@ -65,8 +67,9 @@ Plan& plan_for(const pmi_igemm_args& a) {
     size_t ws = WS_BYTES;
     good = good && hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws, sizeof(ws)) == HIPBLAS_STATUS_SUCCESS;
     int found = 0;
-    good = good && hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.la, p.lb, p.lc, p.ld, pref, 1, &p.heur, &found) == HIPBLAS_STATUS_SUCCESS;
+    good = good && hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.la, p.lb, p.lc, p.ld, pref, MAX_ALGOS, p.heur, &found) == HIPBLAS_STATUS_SUCCESS;
     good = good && found > 0;
+    p.nalgo = found;
     if (pref) hipblasLtMatmulPreferenceDestroy(pref);
   }
   p.ok = good;
@@ -94,7 +97,32 @@ int pmi_gemm_lt(const pmi_igemm_args* a, void* stream) {
   }
   const float alpha = a->alpha, beta = a->R ? 1.f : 0.f;
   const void* C = a->R ? a->R : a->D;
-  const hipblasStatus_t st = hipblasLtMatmul(g_handle, p.desc, &alpha, a->B, p.la, a->A0, p.lb, &beta, C, p.lc, a->D, p.ld, &p.heur.algo,
-                                             g_ws, WS_BYTES, (hipStream_t)stream);
-  return st == HIPBLAS_STATUS_SUCCESS ? PMI_OK : 1;
+  hipStream_t s = (hipStream_t)stream;
+  auto run = [&](int i) {
+    return hipblasLtMatmul(g_handle, p.desc, &alpha, a->B, p.la, a->A0, p.lb, &beta, C, p.lc, a->D, p.ld, &p.heur[i].algo, g_ws, WS_BYTES, s);
+  };
+  if (!p.tuned && p.nalgo > 1 && a->R != a->D && g_tune) {
+    // first use of a shape: time the heuristic's candidates on this stream (the result is the same for each of them) and keep
+    // the fastest; the top heuristic pick is not always the best kernel for fp32-output / residual variants
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+      hipEvent_t e0, e1;
+      (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+      float best_ms = 1e30f;
+      for (int i = 0; i < p.nalgo; ++i) {
+        if (run(i) != HIPBLAS_STATUS_SUCCESS) continue;          // warm-up (code object load)
+        (void)hipEventRecord(e0, s);
+        bool good = true;
+        for (int r = 0; r < 3; ++r) good = good && run(i) == HIPBLAS_STATUS_SUCCESS;
+        (void)hipEventRecord(e1, s);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (good && ms < best_ms) { best_ms = ms; p.best = i; }
+      }
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+      p.tuned = true;
+    }
+  }
+  return run(p.best) == HIPBLAS_STATUS_SUCCESS ? PMI_OK : 1;
 }
