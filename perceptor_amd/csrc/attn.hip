@@ -295,12 +295,12 @@ __global__ __launch_bounds__(64) void vit_attn_fwd_kernel(const u16* __restrict_
 // dQ: wave per 32-query tile.  S^T = K.Q^T and dP^T = V.dO^T put the query on the lane, so lse/delta are lane-local;
 // dS^T (accumulator) is the B operand of dQ^T += K^T . dS^T without any movement.
 template <typename T_>
-__global__ __launch_bounds__(64) void vit_attn_dq_kernel(const u16* __restrict__ q, const u16* __restrict__ k, const u16* __restrict__ v,
-                                                         const u16* __restrict__ kt, const u16* __restrict__ d_o,
-                                                         const float* __restrict__ lse, const float* __restrict__ delta,
-                                                         u16* __restrict__ dqkv, int T, int Tp, int heads, float scale) {
+__device__ __forceinline__ void vit_attn_dq_body(const u16* __restrict__ q, const u16* __restrict__ k, const u16* __restrict__ v,
+                                                 const u16* __restrict__ kt, const u16* __restrict__ d_o,
+                                                 const float* __restrict__ lse, const float* __restrict__ delta,
+                                                 u16* __restrict__ dqkv, int T, int Tp, int heads, float scale, int bx, int bh) {
   const int lane = threadIdx.x, l31 = lane & 31, lhi = lane >> 5;
-  const int t0 = blockIdx.x * 32, bh = blockIdx.y;
+  const int t0 = bx * 32;
   const int64_t rb = (int64_t)bh * Tp;
   uint4 qf[4], dof[4];
 #pragma unroll
@@ -358,12 +358,12 @@ __global__ __launch_bounds__(64) void vit_attn_dq_kernel(const u16* __restrict__
 // dK, dV: wave per 32-key tile.  S = Q.K^T and dP = dO.V^T put the key on the lane and the query on the accumulator rows,
 // so P and dS are the B operands of dV^T += dO^T . P and dK^T += Q^T . dS.
 template <typename T_>
-__global__ __launch_bounds__(64) void vit_attn_dkdv_kernel(const u16* __restrict__ q, const u16* __restrict__ k, const u16* __restrict__ v,
-                                                           const u16* __restrict__ qt, const u16* __restrict__ d_o, const u16* __restrict__ d_ot,
-                                                           const float* __restrict__ lse, const float* __restrict__ delta,
-                                                           u16* __restrict__ dqkv, int T, int Tp, int heads, float scale) {
+__device__ __forceinline__ void vit_attn_dkdv_body(const u16* __restrict__ q, const u16* __restrict__ k, const u16* __restrict__ v,
+                                                   const u16* __restrict__ qt, const u16* __restrict__ d_o, const u16* __restrict__ d_ot,
+                                                   const float* __restrict__ lse, const float* __restrict__ delta,
+                                                   u16* __restrict__ dqkv, int T, int Tp, int heads, float scale, int bx, int bh) {
   const int lane = threadIdx.x, l31 = lane & 31, lhi = lane >> 5;
-  const int s0 = blockIdx.x * 32, bh = blockIdx.y;
+  const int s0 = bx * 32;
   const int64_t rb = (int64_t)bh * Tp;
   uint4 kf[4], vf[4];
 #pragma unroll
@@ -427,6 +427,18 @@ __global__ __launch_bounds__(64) void vit_attn_dkdv_kernel(const u16* __restrict
   }
 }
 
+// dQ and dK/dV of one attention layer in ONE launch (grid.z selects the role): each role alone is 9 x 128 single-wave workgroups
+// -- about one wave per SIMD -- and runs latency-bound; issued together the two roles fill each other's stalls.
+template <typename T_>
+__global__ __launch_bounds__(64) void vit_attn_bwd_kernel(const u16* __restrict__ q, const u16* __restrict__ k, const u16* __restrict__ v,
+                                                          const u16* __restrict__ qt, const u16* __restrict__ kt,
+                                                          const u16* __restrict__ d_o, const u16* __restrict__ d_ot,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          u16* __restrict__ dqkv, int T, int Tp, int heads, float scale) {
+  if (blockIdx.z == 0) vit_attn_dkdv_body<T_>(q, k, v, qt, d_o, d_ot, lse, delta, dqkv, T, Tp, heads, scale, blockIdx.x, blockIdx.y);
+  else vit_attn_dq_body<T_>(q, k, v, kt, d_o, lse, delta, dqkv, T, Tp, heads, scale, blockIdx.x, blockIdx.y);
+}
+
 }  // namespace
 
 #define VIT_BY_DTYPE(KERN, G, B, ...)                                                             \
@@ -459,9 +471,9 @@ extern "C" int pmi_vit_attn_bwd(const void* ws16, const float* lse, const void* 
   dim3 g(Tp / 32, N * heads);
   VIT_BY_DTYPE(vit_do_prep_kernel, g, dim3(256), (const u16*)dout, (const u16*)o, wb, wb + blk, delta, T, Tp, heads);
   PMI_CHECK_LAUNCH();
-  VIT_BY_DTYPE(vit_attn_dq_kernel, g, dim3(64), w, w + blk, w + 2 * blk, w + 4 * blk, wb, lse, delta, (u16*)dqkv, T, Tp, heads, scale);
-  PMI_CHECK_LAUNCH();
-  VIT_BY_DTYPE(vit_attn_dkdv_kernel, g, dim3(64), w, w + blk, w + 2 * blk, w + 3 * blk, wb, wb + blk, lse, delta, (u16*)dqkv, T, Tp, heads, scale);
+  dim3 g2(Tp / 32, N * heads, 2);
+  VIT_BY_DTYPE(vit_attn_bwd_kernel, g2, dim3(64), w, w + blk, w + 2 * blk, w + 3 * blk, w + 4 * blk, wb, wb + blk, lse, delta, (u16*)dqkv, T, Tp,
+               heads, scale);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }

@@ -262,7 +262,11 @@ __global__ __launch_bounds__(256) void spherical_loss_kernel(const float* __rest
                                                              float gscale, float inv_count) {
   __shared__ float red[4];
   __shared__ float e_s[2048], g_s[2048];
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // ONE workgroup walks the samples in order: the scalar loss is a fixed-order sum (a global float atomic per sample would
+  // make its last bits depend on timing); N x K x D is a few thousand operations.
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float ltot = 0.f;
+  for (int n = 0; n < N; ++n) {
   auto block_sum = [&](float v) {
     v = wave_sum(v);
     __syncthreads();
@@ -293,7 +297,10 @@ __global__ __launch_bounds__(256) void spherical_loss_kernel(const float* __rest
   dot = block_sum(dot);
   const float c = mult * inv_count * gscale / nrm;
   for (int d = tid; d < D; d += 256) demb[(int64_t)n * D + d] = c * (g_s[d] - e_s[d] * dot);
-  if (tid == 0) atomicAdd(loss, lsum * mult * inv_count);
+  ltot += lsum;
+  __syncthreads();
+  }
+  if (tid == 0) *loss = ltot * mult * inv_count;
 }
 
 }  // namespace
@@ -386,8 +393,7 @@ extern "C" int pmi_vit_assemble(const float* emb, const float* cls, const float*
 extern "C" int pmi_spherical_loss(const float* emb, const float* tgt, const float* wts, float* loss, float* demb, int N, int K,
                                   int D, int n_total, float mult, float gscale, pmi_stream_t s) {
   if (!emb || !tgt || !wts || !loss || !demb || N <= 0 || K <= 0 || D <= 0 || D > 2048 || n_total < N) return PMI_ERR_ARG;
-  if (hipMemsetAsync(loss, 0, sizeof(float), ST) != hipSuccess) return PMI_ERR_LAUNCH;
-  hipLaunchKernelGGL(spherical_loss_kernel, dim3(N), dim3(256), 0, ST, emb, tgt, wts, loss, demb, N, K, D, mult, gscale,
+  hipLaunchKernelGGL(spherical_loss_kernel, dim3(1), dim3(256), 0, ST, emb, tgt, wts, loss, demb, N, K, D, mult, gscale,
                      1.0f / ((float)n_total * (float)K));
   PMI_CHECK_LAUNCH();
   return PMI_OK;

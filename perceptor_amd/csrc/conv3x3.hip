@@ -254,9 +254,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
   // Instead each wave transposes its tile through LDS (free after the main loop), 64 channels at a time, and writes whole
   // 128-byte lines: 16 bytes per lane, 8 pixels x 128 B per instruction.  The residual is read the same way.
   constexpr int SROW = 144;                    // staged row: 64 channels x 2 B + 16 B pad (16-byte aligned, rows shift by 36 banks)
-  float* const stat = (float*)smem;            // [BN][2] per-channel (sum, sumsq) of this tile
-  float* const bsm = stat + 2 * BN;            // [BN] bias + per-sample bias of the tile's channels
-  char* const stg = smem + 3 * BN * 4 + wid * (64 * SROW);
+  float* const stat = (float*)smem;            // [WM][BN][2] per-channel (sum, sumsq) of each wave row of this tile: plain stores,
+                                               // summed in a fixed order below (LDS float atomics would make the result depend on timing)
+  float* const bsm = stat + WM * 2 * BN;       // [BN] bias + per-sample bias of the tile's channels
+  char* const stg = smem + (WM * 2 + 1) * BN * 4 + wid * (64 * SROW);
   for (int c = tid; c < BN; c += NT) {
     const int n = n0 + c;
     float b = 0.f;
@@ -266,8 +267,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
     }
     bsm[c] = b;
   }
-  if (a.stats)
-    for (int c = tid; c < 2 * BN; c += NT) stat[c] = 0.f;
   __syncthreads();
   const int r8 = lane & 7, rp = lane >> 3;     // write-out role: 16-byte chunk (8 channels) r8 of pixel 8 t + rp
 #pragma unroll
@@ -339,16 +338,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
       for (int k = 0; k < 2; ++k) { const float mine = h5 ? b4[k + 2] : b4[k], other = h5 ? b4[k] : b4[k + 2]; b2[k] = mine + __shfl_xor(other, 32); }
       // the lane now holds the totals of value index h3 * 8 + h4 * 4 + h5 * 2 + k: statistic h3 of channel h4 * 4 + h5 * 2 + k
       const int e0 = (h4 ? 4 : 0) + (h5 ? 2 : 0);
-      atomicAdd(&stat[2 * (cl0 + e0) + (h3 ? 1 : 0)], b2[0]);
-      atomicAdd(&stat[2 * (cl0 + e0 + 1) + (h3 ? 1 : 0)], b2[1]);
+      float* const slot = stat + wm * 2 * BN;
+      slot[2 * (cl0 + e0) + (h3 ? 1 : 0)] = b2[0];
+      slot[2 * (cl0 + e0 + 1) + (h3 ? 1 : 0)] = b2[1];
     }
   }
   STAMP(3);
   if (a.stats) {
     __syncthreads();
     float* o = a.stats + (((int64_t)img * a.stats_p + ty * tiles_x + tx) * a.N + n0) * 2;
-    for (int c = tid; c < 2 * BN; c += NT)
-      if (n0 + (c >> 1) < a.N) o[c] = stat[c];
+    for (int c = tid; c < 2 * BN; c += NT) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) v += stat[w * 2 * BN + c];
+      if (n0 + (c >> 1) < a.N) o[c] = v;
+    }
   }
   }
 #ifdef PMI_STAMPS

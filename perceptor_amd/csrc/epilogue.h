@@ -1,5 +1,5 @@
 // Shared epilogue helpers: per-channel (sum, sum of squares) of a kernel's OUTPUT tile, so the next GroupNorm needs no
-// separate statistics pass over HBM.  Deterministic: every workgroup writes its own partial row.
+// separate statistics pass over HBM.  Deterministic: every wave writes its own LDS slot, every workgroup its own partial row.
 #pragma once
 #include "common.h"
 
@@ -19,13 +19,15 @@ __device__ __forceinline__ float reduce16_over32(const float* v, int lane) {
   return d + __shfl_xor(d, 1);
 }
 
-// Adds the half-wave totals of (sum, sumsq) for one 32-channel block into LDS stat[channel_local][2].
+// Stores the half-wave totals of (sum, sumsq) for one 32-channel block into this wave's LDS slot stat[channel_local][2]:
+// every (channel, statistic) of the block is written by exactly one lane, so the caller can add the slots of the waves
+// that share the channels in a fixed order (no float atomics: results must not depend on timing).
 __device__ __forceinline__ void stats_block_to_lds(const float* ssum, const float* ssq, float* stat, int cbase, int lane) {
   const float r1 = reduce16_over32(ssum, lane), r2 = reduce16_over32(ssq, lane);
   if ((lane & 1) == 0) {
     const int idx = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
     const int c = cbase + 4 * (lane >> 5) + 8 * (idx >> 2) + (idx & 3);
-    atomicAdd(&stat[2 * c], r1);
-    atomicAdd(&stat[2 * c + 1], r2);
+    stat[2 * c] = r1;
+    stat[2 * c + 1] = r2;
   }
 }

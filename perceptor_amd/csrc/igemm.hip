@@ -247,11 +247,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
     return;
   }
   // ---- epilogue: lane = pixel (col), registers = 4 consecutive output channels x 4 groups ----
-  float* const stat = (float*)smem;            // [BN][2] per-channel (sum, sumsq) of this tile (main loop is done with LDS)
-  if (a.stats) {
-    for (int c = tid; c < 2 * BN; c += 256) stat[c] = 0.f;
-    __syncthreads();
-  }
+  float* const stat = (float*)smem;            // [2 wave rows][BN][2] per-channel (sum, sumsq) of this tile (main loop is done with LDS)
   int64_t rrow[2];
   const float* nbp[2];
   int mrow[2];
@@ -335,14 +331,14 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
         for (int e = 0; e < 4; ++e) { ssum[4 * g + e] += v[e]; ssq[4 * g + e] += v[e] * v[e]; }
       }
     }
-    if (a.stats) stats_block_to_lds(ssum, ssq, stat, wc * 64 + j * 32, lane);
+    if (a.stats) stats_block_to_lds(ssum, ssq, stat + wr * 2 * BN, wc * 64 + j * 32, lane);
   }
   if (a.stats) {
     __syncthreads();
     const int img = m0 / a.hw, prow = (m0 - img * a.hw) / BM;
     float* o = a.stats + ((int64_t)(img * a.stats_p + prow) * a.N + n0) * 2;
     for (int c = tid; c < 2 * BN; c += 256)
-      if (n0 + (c >> 1) < a.N) o[c] = stat[c];
+      if (n0 + (c >> 1) < a.N) o[c] = stat[c] + stat[2 * BN + c];
   }
 #ifdef PMI_STAMPS
   __syncthreads();

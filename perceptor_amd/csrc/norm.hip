@@ -11,10 +11,8 @@ constexpr int MAXC = 4096;
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const u16* __restrict__ x, const u16* __restrict__ x1, int C0,
                                                        float* __restrict__ ws, int HW, int C, int G, int nchunk) {
-  __shared__ float s_sum[MAXC], s_sq[MAXC];
+  __shared__ float s_sum[MAXC], s_sq[MAXC];      // [PPI][C] slots, one per pixel lane (PPI * C <= MAXC): no float atomics
   const int tid = threadIdx.x, chunk = blockIdx.x, n = blockIdx.y;
-  for (int c = tid; c < C; c += 256) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
-  __syncthreads();
   const int C8 = C >> 3;
   const int TPP = C8 < 256 ? C8 : 256;      // threads per pixel
   const int PPI = 256 / TPP;                // pixels per iteration
@@ -37,12 +35,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const u16* __restrict__ x
         for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { atomicAdd(&s_sum[c8 * 8 + e], s[e]); atomicAdd(&s_sq[c8 * 8 + e], q[e]); }
+      for (int e = 0; e < 8; ++e) { s_sum[my_p * C + c8 * 8 + e] = s[e]; s_sq[my_p * C + c8 * 8 + e] = q[e]; }
     }
   }
   __syncthreads();
   float* o = ws + ((int64_t)n * nchunk + chunk) * C * 2;
-  for (int c = tid; c < C; c += 256) { o[2 * c] = s_sum[c]; o[2 * c + 1] = s_sq[c]; }
+  for (int c = tid; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int pl = 0; pl < PPI; ++pl) { a += s_sum[pl * C + c]; b += s_sq[pl * C + c]; }     // fixed order
+    o[2 * c] = a; o[2 * c + 1] = b;
+  }
 }
 
 // ---- finalize: y = act(x * a[n][c] + b[n][c]) with affine and FiLM folded in -------------------

@@ -29,8 +29,12 @@ def lincomb2(a, ca, b=None, cb=None, cc=None):
     dev = a.device
     out = torch.empty_like(a)
     bb = _prep(b) if b is not None else None
-    call("pmi_lincomb2", ptr(a), ptr(bb), ptr(_vec(ca, n, dev)), ptr(_vec(cb, n, dev)) if b is not None else None,
-         ptr(_vec(cc, n, dev)) if cc is not None else None, ptr(out), n, chw)
+    # the coefficient vectors must stay referenced until the launch is queued: an unnamed temporary goes back to the caching
+    # allocator as soon as ptr() returns and the NEXT temporary reuses (and overwrites) its block
+    va = _vec(ca, n, dev)
+    vb = _vec(cb, n, dev) if b is not None else None
+    vc = _vec(cc, n, dev) if cc is not None else None
+    call("pmi_lincomb2", ptr(a), ptr(bb), ptr(va), ptr(vb), ptr(vc), ptr(out), n, chw)
     return out
 
 
@@ -38,7 +42,8 @@ def clamp(a, lo, hi):
     a = _prep(a)
     n, chw = a.shape[0], a[0].numel()
     out = torch.empty_like(a)
-    call("pmi_clamp", ptr(a), ptr(_vec(lo, n, a.device)), ptr(_vec(hi, n, a.device)), ptr(out), n, chw)
+    vlo, vhi = _vec(lo, n, a.device), _vec(hi, n, a.device)      # named: see lincomb2
+    call("pmi_clamp", ptr(a), ptr(vlo), ptr(vhi), ptr(out), n, chw)
     return out
 
 
@@ -61,5 +66,6 @@ def guided_update(pred, grad, s_f, scale: float, clamp_value: float):
     pred, grad = _prep(pred), _prep(grad)
     n, chw = pred.shape[0], pred[0].numel()
     out = torch.empty_like(pred)
-    call("pmi_guided_update", ptr(pred), ptr(grad), ptr(_vec(s_f, n, pred.device)), float(scale), float(clamp_value), ptr(out), n, chw)
+    vs = _vec(s_f, n, pred.device)
+    call("pmi_guided_update", ptr(pred), ptr(grad), ptr(vs), float(scale), float(clamp_value), ptr(out), n, chw)
     return out

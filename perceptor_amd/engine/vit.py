@@ -200,7 +200,8 @@ class VitEngine:
         d = width // heads
         scale = float(d) ** -0.5
         d16 = torch.empty((n, out), dtype=tdt, device=dev)
-        call("pmi_cast_f32_to_16", ptr(d_emb.contiguous()), ptr(d16), n * out, ACT_NONE, dt)
+        d_emb = d_emb.contiguous()          # named: a temporary would be released before the launch is queued
+        call("pmi_cast_f32_to_16", ptr(d_emb), ptr(d16), n * out, ACT_NONE, dt)
         dy_post = ops.igemm(d16, self.proj.bwd, out_f32=True)                      # [n, width]
         g32 = torch.zeros((m, width), dtype=torch.float32, device=dev)
         g16 = torch.zeros((m, width), dtype=tdt, device=dev)

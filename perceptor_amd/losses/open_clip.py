@@ -75,7 +75,8 @@ class _SphericalBase(LossInterface):
         k, dim = self.encodings.shape
         loss = torch.empty(1, dtype=torch.float32, device=self.device)
         demb = torch.empty_like(emb)
-        call("pmi_spherical_loss", ptr(emb), ptr(self.encodings.data.contiguous()), ptr(self.weights.data.contiguous()), ptr(loss), ptr(demb),
+        enc, wts = self.encodings.data.contiguous(), self.weights.data.contiguous()
+        call("pmi_spherical_loss", ptr(emb), ptr(enc), ptr(wts), ptr(loss), ptr(demb),
              n, k, dim, int(n_total or n), float(self.multiplier), float(eng.gscale))
         return loss[0], eng.backward(demb)
 

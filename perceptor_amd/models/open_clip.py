@@ -41,7 +41,8 @@ class _EncodeImages(torch.autograd.Function):
         ctx.save_for_backward(emb)
         if normalize:
             out = torch.empty_like(emb)
-            call("pmi_l2norm_rows", ptr(emb.contiguous()), ptr(out), emb.shape[0], emb.shape[1], 1.0)
+            emb = emb.contiguous()
+            call("pmi_l2norm_rows", ptr(emb), ptr(out), emb.shape[0], emb.shape[1], 1.0)
             return out
         return emb.clone()
 
@@ -132,7 +133,8 @@ class OpenCLIP(torch.nn.Module):
         emb = self.engine.forward(images)
         if normalize:
             out = torch.empty_like(emb)
-            call("pmi_l2norm_rows", ptr(emb.contiguous()), ptr(out), emb.shape[0], emb.shape[1], 1.0)
+            emb = emb.contiguous()
+            call("pmi_l2norm_rows", ptr(emb), ptr(out), emb.shape[0], emb.shape[1], 1.0)
             return out
         return emb
 

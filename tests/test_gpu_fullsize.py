@@ -1,0 +1,77 @@
+"""GPU: the benchmark's full-size workload (BASELINE.json configs[4] per-GPU share: GuidedDiffusion "standard" UNet at
+512x512, batch 8, OpenCLIP ViT-L/14 guidance, bf16) checked through size-independent properties -- the CPU oracle cannot run
+this size in test time, so instead of values the test pins what must hold at ANY size:
+
+  * determinism: the same inputs twice give bit-identical outputs (every reduction in the kernels has a fixed order);
+  * chain independence (the basis of the replica sharding): permuting the batch permutes the outputs bit-exactly,
+    and a shard with n_total = N_global reproduces its slice of the full-batch guidance gradient;
+  * the fused sampler algebra at full size: x = denoised * alpha + eps * sigma reproduces the input (Predictions round trip,
+    guided_diffusion/predictions.py:51-59), and a DDIM step to the same index is the identity;
+  * everything finite, guidance gradient non-zero for every chain.
+Value parity for the same engines is pinned at 128x128 against the reference's golden vectors in test_gpu_adm.py / test_gpu_clip.py.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def workload():
+    from perceptor_amd import losses, models
+    from perceptor_amd.utils.synth import seeded_noise
+    dev = torch.device("cuda:0")
+    model = models.GuidedDiffusion("standard", dtype="bf16").to(dev)
+    clip = losses.OpenCLIP("ViT-L-14", "synthetic", dtype="bf16").to(dev)
+    clip.add_encodings_(torch.nn.functional.normalize(seeded_noise((2, clip.model.output_dim), 7)).to(dev))
+    images = (seeded_noise((8, 3, 512, 512), 1234) * 0.5 + 0.5).to(dev)
+    sched = model.schedule_indices(n_steps=50, rho=7.0)
+    return model, clip, images, sched
+
+
+def test_full_size_unet_is_deterministic_and_chain_independent(workload):
+    model, _, images, sched = workload
+    fi = sched[3][0]
+    eps0 = model.predicted_noise(images, fi)
+    eps1 = model.predicted_noise(images, fi)
+    assert eps0.shape == (8, 3, 512, 512) and bool(torch.isfinite(eps0).all())
+    assert torch.equal(eps0, eps1), "same input, different bits: a reduction order depends on scheduling"
+    perm = torch.tensor([5, 2, 7, 0, 3, 6, 1, 4], device=images.device)
+    eps_p = model.predicted_noise(images[perm].contiguous(), fi)
+    assert torch.equal(eps_p, eps0[perm]), "a chain's output depends on its position in the batch"
+    assert float(eps0.std()) > 1e-3
+
+
+def test_full_size_predictions_round_trip_and_identity_step(workload):
+    model, _, images, sched = workload
+    fi, ti = sched[3]
+    pred = model.predictions(images, fi)
+    a, s = pred.from_alphas, pred.from_sigmas
+    x = pred.from_diffused_xs
+    assert float((x - (images * 2 - 1)).abs().max()) <= 1e-6
+    recon = pred.denoised_xs * a + pred.predicted_noise * s
+    assert float((recon - x).abs().max()) <= 2e-5 * float(x.abs().max()), "x != x0_hat*alpha + eps*sigma"
+    same = pred.step(fi)                                  # DDIM to the same index, eta = 0: identity on the diffused images
+    assert float((same - images).abs().max()) <= 2e-5
+    nxt = pred.step(ti)
+    assert nxt.shape == images.shape and bool(torch.isfinite(nxt).all())
+
+
+def test_full_size_clip_guidance_gradient_shards_exactly(workload):
+    model, clip, images, sched = workload
+    den = model.predictions(images, sched[3][0]).denoised_images
+    loss, grad = clip.loss_and_grad(den, n_total=8)
+    loss2, grad2 = clip.loss_and_grad(den, n_total=8)
+    assert torch.equal(grad, grad2) and float(loss) == float(loss2)
+    assert bool(torch.isfinite(grad).all())
+    per_chain = grad.flatten(1).norm(dim=1)
+    assert bool((per_chain > 0).all()), "a chain received no guidance"
+    # rank r of 2 holds chains [4r, 4r+4): with n_total = 8 its gradient is its slice of the single-process gradient
+    for r in range(2):
+        _, g = clip.loss_and_grad(den[4 * r:4 * r + 4].contiguous(), n_total=8)
+        err = float((g - grad[4 * r:4 * r + 4]).abs().max())
+        assert err <= 2e-2 * float(grad.abs().max()), (r, err)   # bf16 GEMMs at M = 4 x 257 pick other library tiles: rounding-level differences only
+        cos = torch.nn.functional.cosine_similarity(g.flatten(), grad[4 * r:4 * r + 4].flatten(), dim=0)
+        assert float(cos) >= 0.9999
+    guided = model.predictions(images, sched[3][0]).guided(grad, guidance_scale=0.5, clamp_value=1e-6)
+    assert bool(torch.isfinite(guided.predicted_noise).all())
