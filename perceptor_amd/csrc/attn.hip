@@ -157,13 +157,21 @@ extern "C" int pmi_attn_d64(const void* q, const void* k, const void* vt, void* 
 // each recompute the 32x32 probability blocks on MFMA (no T x T matrix in HBM, no transposes, no atomics):
 //   dq kernel   : one wave per 32-query tile, loops over key tiles    -> dQ
 //   dkdv kernel : one wave per 32-key tile,   loops over query tiles  -> dK, dV
-// Layouts (all 16-bit, Tp = T rounded up to 32, zero filled): Q,K,V,dO [B*H][Tp][64]; Qt,Kt,Vt,dOt [B*H][64][Tp];
+// Layouts (all 16-bit, Tp = T rounded up to 32, zero filled): Q,K,V,dO [B*H][Tp][64]; Qt,Kt,Vt,dOt [B*H][Tp/32][fragment order, see tfrag];
 // lse, delta fp32 [B*H][Tp]  (delta[t] = sum_d dO[t][d] * O[t][d]).
 // Replaces nn.MultiheadAttention forward + autograd in the CLIP tower (ruclip/model.py:40-52).
 // =====================================================================================================================
 namespace {
 
-// qkv [N][T][3C] with channels (which, head, d) -> Q,K,V [bh][Tp][64] and Qt,Kt,Vt [bh][64][Tp]
+// The transposed operands (Qt, Kt, Vt, dOt: head dim on the MFMA rows, tokens on k) are stored in FRAGMENT order: the 8 tokens a
+// lane needs for one MFMA A operand, {16 ks + 4 lhi + 0..3} and {16 ks + 8 + 4 lhi + 0..3} of a 32-token block (the k order of an
+// accumulator tile re-used as B operand), are 16 contiguous bytes, and the 64 lanes of a wave are contiguous: one coalesced 1 KB
+// load per fragment.  With plain [bh][64][Tp] rows every fragment load touched 64 separate 8-byte pieces 2*Tp bytes apart.
+__device__ __forceinline__ int64_t tfrag(int bh, int ntb, int tb, int ks, int db, int lhi, int l31) {
+  return ((((((int64_t)bh * ntb + tb) * 2 + ks) * 2 + db) * 2 + lhi) * 32 + l31) * 8;
+}
+
+// qkv [N][T][3C] with channels (which, head, d) -> Q,K,V [bh][Tp][64] and Qt,Kt,Vt in fragment order (tfrag)
 template <typename T_>
 __global__ __launch_bounds__(256) void vit_qkv_split_kernel(const u16* __restrict__ qkv, u16* __restrict__ q, u16* __restrict__ k,
                                                             u16* __restrict__ v, u16* __restrict__ qt, u16* __restrict__ kt,
@@ -182,13 +190,13 @@ __global__ __launch_bounds__(256) void vit_qkv_split_kernel(const u16* __restric
     *(uint4*)(&s[w][row][ch * 8]) = val;
   }
   __syncthreads();
-  const int d = tid >> 2, tc = tid & 3;
+  const int d = tid >> 2, tc = tid & 3, fks = tc >> 1, flhi = tc & 1;
 #pragma unroll
   for (int w = 0; w < 3; ++w) {
     u16 e[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) e[j] = s[w][tc * 8 + j][d];
-    *(uint4*)(dstt[w] + ((int64_t)bh * 64 + d) * Tp + t0 + tc * 8) =
+    for (int j = 0; j < 8; ++j) e[j] = s[w][16 * fks + 4 * flhi + (j & 3) + 8 * (j >> 2)][d];
+    *(uint4*)(dstt[w] + tfrag(bh, Tp >> 5, blockIdx.x, fks, d >> 5, flhi, d & 31)) =
         make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
   }
 }
@@ -216,11 +224,11 @@ __global__ __launch_bounds__(256) void vit_do_prep_kernel(const u16* __restrict_
   p += __shfl_xor(p, 1); p += __shfl_xor(p, 2); p += __shfl_xor(p, 4);
   if (ch == 0) delta[(int64_t)bh * Tp + t] = p;
   __syncthreads();
-  const int d = tid >> 2, tc = tid & 3;
+  const int d = tid >> 2, tc = tid & 3, fks = tc >> 1, flhi = tc & 1;
   u16 e[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) e[j] = s[tc * 8 + j][d];
-  *(uint4*)(d_ot + ((int64_t)bh * 64 + d) * Tp + t0 + tc * 8) =
+  for (int j = 0; j < 8; ++j) e[j] = s[16 * fks + 4 * flhi + (j & 3) + 8 * (j >> 2)][d];
+  *(uint4*)(d_ot + tfrag(bh, Tp >> 5, blockIdx.x, fks, d >> 5, flhi, d & 31)) =
       make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
 }
 
@@ -232,7 +240,6 @@ __global__ __launch_bounds__(64) void vit_attn_fwd_kernel(const u16* __restrict_
   const int t0 = blockIdx.x * 32, bh = blockIdx.y;
   const u16* qb = q + ((int64_t)bh * Tp + t0 + l31) * 64 + 8 * lhi;
   const u16* kb = k + (int64_t)bh * Tp * 64 + 8 * lhi;
-  const u16* vb = vt + (int64_t)bh * 64 * Tp;
   uint4 qf[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const uint4*)(qb + kk * 16);
@@ -268,12 +275,9 @@ __global__ __launch_bounds__(64) void vit_attn_fwd_kernel(const u16* __restrict_
 #pragma unroll
       for (int j = 0; j < 8; ++j) pf[j] = sacc[8 * ks + j];
       const uint4 pfrag = pack8<T_>(pf);
-      const int sk = s0 + 16 * ks + 4 * lhi;
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        const u16* vp = vb + (int64_t)(db * 32 + l31) * Tp + sk;
-        const uint2 lo = *(const uint2*)vp, hi = *(const uint2*)(vp + 8);
-        const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        const uint4 vf = *(const uint4*)(vt + tfrag(bh, Tp >> 5, s0 >> 5, ks, db, lhi, l31));
         if (db == 0) o0 = T_::mfma32(vf, pfrag, o0); else o1 = T_::mfma32(vf, pfrag, o1);
       }
     }
@@ -333,12 +337,9 @@ __device__ __forceinline__ void vit_attn_dq_body(const u16* __restrict__ q, cons
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = sacc[8 * ks + j];
       const uint4 dsf = pack8<T_>(f);
-      const int sk = s0 + 16 * ks + 4 * lhi;
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        const u16* kp = kt + ((int64_t)bh * 64 + db * 32 + l31) * Tp + sk;
-        const uint2 lo = *(const uint2*)kp, hi = *(const uint2*)(kp + 8);
-        const uint4 kf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        const uint4 kf = *(const uint4*)(kt + tfrag(bh, Tp >> 5, s0 >> 5, ks, db, lhi, l31));
         if (db == 0) g0 = T_::mfma32(kf, dsf, g0); else g1 = T_::mfma32(kf, dsf, g1);
       }
     }
@@ -399,14 +400,10 @@ __device__ __forceinline__ void vit_attn_dkdv_body(const u16* __restrict__ q, co
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = sacc[8 * ks + j];
       const uint4 dsf = pack8<T_>(f);
-      const int tk = t0 + 16 * ks + 4 * lhi;
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        const u16* dp_ = d_ot + ((int64_t)bh * 64 + db * 32 + l31) * Tp + tk;
-        const u16* qp_ = qt + ((int64_t)bh * 64 + db * 32 + l31) * Tp + tk;
-        const uint2 a0 = *(const uint2*)dp_, a1 = *(const uint2*)(dp_ + 8);
-        const uint2 b0 = *(const uint2*)qp_, b1 = *(const uint2*)(qp_ + 8);
-        const uint4 dof = make_uint4(a0.x, a0.y, a1.x, a1.y), qf = make_uint4(b0.x, b0.y, b1.x, b1.y);
+        const int64_t fo = tfrag(bh, Tp >> 5, t0 >> 5, ks, db, lhi, l31);
+        const uint4 dof = *(const uint4*)(d_ot + fo), qf = *(const uint4*)(qt + fo);
         if (db == 0) { dv0 = T_::mfma32(dof, pfrag, dv0); dk0 = T_::mfma32(qf, dsf, dk0); }
         else { dv1 = T_::mfma32(dof, pfrag, dv1); dk1 = T_::mfma32(qf, dsf, dk1); }
       }
