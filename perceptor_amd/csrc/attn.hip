@@ -13,7 +13,15 @@
 
 namespace {
 
-// qkv [N][T][3C] -> Q,K [N*heads][Tp][64], Vt [N*heads][64][Tp]; zero fill for t >= T.
+// Transposed operands (head dim on the MFMA rows, tokens on k) are stored in FRAGMENT order: the 8 tokens a lane needs for one
+// MFMA A operand, {16 ks + 4 lhi + 0..3} and {16 ks + 8 + 4 lhi + 0..3} of a 32-token block (the k order of an accumulator tile
+// re-used as B operand), are 16 contiguous bytes and the 64 lanes of a wave are contiguous: one coalesced 1 KB load per fragment.
+// With plain [bh][64][Tp] rows every fragment load touched 64 separate 8-byte pieces 2*Tp bytes apart.
+__device__ __forceinline__ int64_t tfrag(int bh, int ntb, int tb, int ks, int db, int lhi, int l31) {
+  return ((((((int64_t)bh * ntb + tb) * 2 + ks) * 2 + db) * 2 + lhi) * 32 + l31) * 8;
+}
+
+// qkv [N][T][3C] -> Q,K [N*heads][Tp][64], Vt [N*heads][Tp/32][fragment order]; zero fill for t >= T.
 template <typename T_>
 __global__ __launch_bounds__(256) void qkv_split_kernel(const u16* __restrict__ qkv, u16* __restrict__ q,
                                                         u16* __restrict__ k, u16* __restrict__ vt, int T, int Tp,
@@ -37,12 +45,12 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const u16* __restrict__ 
   *(uint4*)(k + o) = vk;
   *(uint4*)(&sv[row][ch * 8]) = vv;
   __syncthreads();
-  const int d = tid >> 2, tc = tid & 3;
+  const int d = tid >> 2, tc = tid & 3, fks = tc >> 1, flhi = tc & 1;
   u16 e[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) e[j] = sv[tc * 8 + j][d];
+  for (int j = 0; j < 8; ++j) e[j] = sv[16 * fks + 4 * flhi + (j & 3) + 8 * (j >> 2)][d];
   uint4 out = make_uint4(e[0] | (e[1] << 16), e[2] | (e[3] << 16), e[4] | (e[5] << 16), e[6] | (e[7] << 16));
-  *(uint4*)(vt + ((int64_t)bh * 64 + d) * Tp + t0 + tc * 8) = out;
+  *(uint4*)(vt + tfrag(bh, Tp >> 5, blockIdx.x, fks, d >> 5, flhi, d & 31)) = out;
 }
 
 template <typename T_>
@@ -53,7 +61,6 @@ __global__ __launch_bounds__(64) void attn_d64_kernel(const u16* __restrict__ q,
   const int t0 = blockIdx.x * 32, bh = blockIdx.y;
   const u16* qb = q + ((int64_t)bh * Tp + t0 + l31) * 64 + 8 * lhi;
   const u16* kb = k + (int64_t)bh * Tp * 64 + 8 * lhi;
-  const u16* vb = vt + (int64_t)bh * 64 * Tp;
 
   uint4 qf[4];
 #pragma unroll
@@ -103,13 +110,9 @@ __global__ __launch_bounds__(64) void attn_d64_kernel(const u16* __restrict__ q,
 #pragma unroll
       for (int j = 0; j < 8; ++j) pf[j] = sacc[8 * ks + j];
       const uint4 pfrag = pack8<T_>(pf);
-      const int sk = s0 + 16 * ks + 4 * lhi;
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        const u16* vp = vb + (int64_t)(db * 32 + l31) * Tp + sk;
-        const uint2 lo = *(const uint2*)vp;
-        const uint2 hi = *(const uint2*)(vp + 8);
-        const uint4 vf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        const uint4 vf = *(const uint4*)(vt + tfrag(bh, Tp >> 5, s0 >> 5, ks, db, lhi, l31));
         if (db == 0) o0 = T_::mfma32(vf, pfrag, o0);
         else o1 = T_::mfma32(vf, pfrag, o1);
       }
@@ -162,14 +165,6 @@ extern "C" int pmi_attn_d64(const void* q, const void* k, const void* vt, void* 
 // Replaces nn.MultiheadAttention forward + autograd in the CLIP tower (ruclip/model.py:40-52).
 // =====================================================================================================================
 namespace {
-
-// The transposed operands (Qt, Kt, Vt, dOt: head dim on the MFMA rows, tokens on k) are stored in FRAGMENT order: the 8 tokens a
-// lane needs for one MFMA A operand, {16 ks + 4 lhi + 0..3} and {16 ks + 8 + 4 lhi + 0..3} of a 32-token block (the k order of an
-// accumulator tile re-used as B operand), are 16 contiguous bytes, and the 64 lanes of a wave are contiguous: one coalesced 1 KB
-// load per fragment.  With plain [bh][64][Tp] rows every fragment load touched 64 separate 8-byte pieces 2*Tp bytes apart.
-__device__ __forceinline__ int64_t tfrag(int bh, int ntb, int tb, int ks, int db, int lhi, int l31) {
-  return ((((((int64_t)bh * ntb + tb) * 2 + ks) * 2 + db) * 2 + lhi) * 32 + l31) * 8;
-}
 
 // qkv [N][T][3C] with channels (which, head, d) -> Q,K,V [bh][Tp][64] and Qt,Kt,Vt in fragment order (tfrag)
 template <typename T_>
