@@ -21,7 +21,13 @@ __device__ __forceinline__ int64_t tfrag(int bh, int ntb, int tb, int ks, int db
   return ((((((int64_t)bh * ntb + tb) * 2 + ks) * 2 + db) * 2 + lhi) * 32 + l31) * 8;
 }
 
-// qkv [N][T][3C] -> Q,K [N*heads][Tp][64], Vt [N*heads][Tp/32][fragment order]; zero fill for t >= T.
+// The row operands (tokens on the MFMA rows, head dim on k: Q, K, V, dO) use the same idea: element (t, c) of a 32-token block
+// lives at [block][kk = c / 16][lhi = (c / 8) & 1][t & 31][c & 7], so the fragment of step kk is one contiguous 1 KB run.
+__device__ __forceinline__ int64_t rfrag(int bh, int ntb, int tb, int kk, int lhi, int l31) {
+  return ((((((int64_t)bh * ntb + tb) * 4 + kk) * 2 + lhi) * 32 + l31) * 8);
+}
+
+// qkv [N][T][3C] -> Q,K [N*heads][Tp/32][fragment order, rfrag], Vt [N*heads][Tp/32][fragment order, tfrag]; zero fill for t >= T.
 template <typename T_>
 __global__ __launch_bounds__(256) void qkv_split_kernel(const u16* __restrict__ qkv, u16* __restrict__ q,
                                                         u16* __restrict__ k, u16* __restrict__ vt, int T, int Tp,
@@ -40,7 +46,7 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const u16* __restrict__ 
     const u16* src = qkv + ((int64_t)n * T + t) * 3 * C + ch * 8;
     vq = *(const uint4*)(src + qoff); vk = *(const uint4*)(src + koff); vv = *(const uint4*)(src + voff);
   }
-  const int64_t o = ((int64_t)bh * Tp + t) * 64 + ch * 8;
+  const int64_t o = rfrag(bh, Tp >> 5, blockIdx.x, ch >> 1, ch & 1, row);
   *(uint4*)(q + o) = vq;
   *(uint4*)(k + o) = vk;
   *(uint4*)(&sv[row][ch * 8]) = vv;
@@ -59,12 +65,10 @@ __global__ __launch_bounds__(64) void attn_d64_kernel(const u16* __restrict__ q,
                                                       int heads, float scale) {
   const int lane = threadIdx.x, l31 = lane & 31, lhi = lane >> 5;
   const int t0 = blockIdx.x * 32, bh = blockIdx.y;
-  const u16* qb = q + ((int64_t)bh * Tp + t0 + l31) * 64 + 8 * lhi;
-  const u16* kb = k + (int64_t)bh * Tp * 64 + 8 * lhi;
-
+  const int ntb = Tp >> 5;
   uint4 qf[4];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const uint4*)(qb + kk * 16);
+  for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const uint4*)(q + rfrag(bh, ntb, blockIdx.x, kk, lhi, l31));
 
   f32x16 o0, o1;
 #pragma unroll
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(64) void attn_d64_kernel(const u16* __restrict__ q,
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const uint4 kf = *(const uint4*)(kb + (int64_t)(s0 + l31) * 64 + kk * 16);
+      const uint4 kf = *(const uint4*)(k + rfrag(bh, ntb, s0 >> 5, kk, lhi, l31));
       sacc = T_::mfma32(kf, qf[kk], sacc);
     }
     float mx = -1e30f;
@@ -160,7 +164,7 @@ extern "C" int pmi_attn_d64(const void* q, const void* k, const void* vt, void* 
 // each recompute the 32x32 probability blocks on MFMA (no T x T matrix in HBM, no transposes, no atomics):
 //   dq kernel   : one wave per 32-query tile, loops over key tiles    -> dQ
 //   dkdv kernel : one wave per 32-key tile,   loops over query tiles  -> dK, dV
-// Layouts (all 16-bit, Tp = T rounded up to 32, zero filled): Q,K,V,dO [B*H][Tp][64]; Qt,Kt,Vt,dOt [B*H][Tp/32][fragment order, see tfrag];
+// Layouts (all 16-bit, Tp = T rounded up to 32, zero filled): Q,K,V,dO [B*H][Tp/32][fragment order, see rfrag]; Qt,Kt,Vt,dOt [B*H][Tp/32][fragment order, see tfrag];
 // lse, delta fp32 [B*H][Tp]  (delta[t] = sum_d dO[t][d] * O[t][d]).
 // Replaces nn.MultiheadAttention forward + autograd in the CLIP tower (ruclip/model.py:40-52).
 // =====================================================================================================================
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256) void vit_qkv_split_kernel(const u16* __restric
   for (int w = 0; w < 3; ++w) {
     uint4 val = make_uint4(0, 0, 0, 0);
     if (t < T) val = *(const uint4*)(qkv + ((int64_t)n * T + t) * 3 * C + w * C + h * 64 + ch * 8);
-    *(uint4*)(dst[w] + ((int64_t)bh * Tp + t) * 64 + ch * 8) = val;
+    *(uint4*)(dst[w] + rfrag(bh, Tp >> 5, blockIdx.x, ch >> 1, ch & 1, row)) = val;
     *(uint4*)(&s[w][row][ch * 8]) = val;
   }
   __syncthreads();
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(256) void vit_do_prep_kernel(const u16* __restrict_
     val = *(const uint4*)(dout + ((int64_t)n * T + t) * C + h * 64 + ch * 8);
     ov = *(const uint4*)(o + ((int64_t)n * T + t) * C + h * 64 + ch * 8);
   }
-  *(uint4*)(d_o + ((int64_t)bh * Tp + t) * 64 + ch * 8) = val;
+  *(uint4*)(d_o + rfrag(bh, Tp >> 5, blockIdx.x, ch >> 1, ch & 1, row)) = val;
   *(uint4*)(&s[row][ch * 8]) = val;
   float a[8], b[8], p = 0.f;
   unpack8<T_>(val, a); unpack8<T_>(ov, b);
@@ -233,11 +237,10 @@ __global__ __launch_bounds__(64) void vit_attn_fwd_kernel(const u16* __restrict_
                                                           u16* __restrict__ out, float* __restrict__ lse, int T, int Tp, int heads, float scale) {
   const int lane = threadIdx.x, l31 = lane & 31, lhi = lane >> 5;
   const int t0 = blockIdx.x * 32, bh = blockIdx.y;
-  const u16* qb = q + ((int64_t)bh * Tp + t0 + l31) * 64 + 8 * lhi;
-  const u16* kb = k + (int64_t)bh * Tp * 64 + 8 * lhi;
+  const int ntb = Tp >> 5;
   uint4 qf[4];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const uint4*)(qb + kk * 16);
+  for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const uint4*)(q + rfrag(bh, ntb, blockIdx.x, kk, lhi, l31));
   f32x16 o0, o1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(64) void vit_attn_fwd_kernel(const u16* __restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) sacc = T_::mfma32(*(const uint4*)(kb + (int64_t)(s0 + l31) * 64 + kk * 16), qf[kk], sacc);
+    for (int kk = 0; kk < 4; ++kk) sacc = T_::mfma32(*(const uint4*)(k + rfrag(bh, ntb, s0 >> 5, kk, lhi, l31)), qf[kk], sacc);
     float mx = -1e30f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -304,8 +307,8 @@ __device__ __forceinline__ void vit_attn_dq_body(const u16* __restrict__ q, cons
   uint4 qf[4], dof[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    qf[kk] = *(const uint4*)(q + (rb + t0 + l31) * 64 + kk * 16 + 8 * lhi);
-    dof[kk] = *(const uint4*)(d_o + (rb + t0 + l31) * 64 + kk * 16 + 8 * lhi);
+    qf[kk] = *(const uint4*)(q + rfrag(bh, Tp >> 5, bx, kk, lhi, l31));
+    dof[kk] = *(const uint4*)(d_o + rfrag(bh, Tp >> 5, bx, kk, lhi, l31));
   }
   const float my_lse = lse[rb + t0 + l31], my_delta = delta[rb + t0 + l31];
   f32x16 g0, g1;
@@ -317,8 +320,8 @@ __device__ __forceinline__ void vit_attn_dq_body(const u16* __restrict__ q, cons
     for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      sacc = T_::mfma32(*(const uint4*)(k + (rb + s0 + l31) * 64 + kk * 16 + 8 * lhi), qf[kk], sacc);
-      dp = T_::mfma32(*(const uint4*)(v + (rb + s0 + l31) * 64 + kk * 16 + 8 * lhi), dof[kk], dp);
+      sacc = T_::mfma32(*(const uint4*)(k + rfrag(bh, Tp >> 5, s0 >> 5, kk, lhi, l31)), qf[kk], sacc);
+      dp = T_::mfma32(*(const uint4*)(v + rfrag(bh, Tp >> 5, s0 >> 5, kk, lhi, l31)), dof[kk], dp);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -364,8 +367,8 @@ __device__ __forceinline__ void vit_attn_dkdv_body(const u16* __restrict__ q, co
   uint4 kf[4], vf[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
-    kf[kk] = *(const uint4*)(k + (rb + s0 + l31) * 64 + kk * 16 + 8 * lhi);
-    vf[kk] = *(const uint4*)(v + (rb + s0 + l31) * 64 + kk * 16 + 8 * lhi);
+    kf[kk] = *(const uint4*)(k + rfrag(bh, Tp >> 5, bx, kk, lhi, l31));
+    vf[kk] = *(const uint4*)(v + rfrag(bh, Tp >> 5, bx, kk, lhi, l31));
   }
   const bool key_ok = s0 + l31 < T;
   f32x16 dk0, dk1, dv0, dv1;
@@ -377,8 +380,8 @@ __device__ __forceinline__ void vit_attn_dkdv_body(const u16* __restrict__ q, co
     for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      sacc = T_::mfma32(*(const uint4*)(q + (rb + t0 + l31) * 64 + kk * 16 + 8 * lhi), kf[kk], sacc);     // rows = queries, lane = key
-      dp = T_::mfma32(*(const uint4*)(d_o + (rb + t0 + l31) * 64 + kk * 16 + 8 * lhi), vf[kk], dp);
+      sacc = T_::mfma32(*(const uint4*)(q + rfrag(bh, Tp >> 5, t0 >> 5, kk, lhi, l31)), kf[kk], sacc);     // rows = queries, lane = key
+      dp = T_::mfma32(*(const uint4*)(d_o + rfrag(bh, Tp >> 5, t0 >> 5, kk, lhi, l31)), vf[kk], dp);
     }
     float pf[16];
 #pragma unroll
