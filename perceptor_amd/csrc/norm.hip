@@ -48,49 +48,15 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const u16* __restrict__ x
 }
 
 // ---- finalize: y = act(x * a[n][c] + b[n][c]) with affine and FiLM folded in -------------------
-// one workgroup per (sample, group); partials are per channel: s0[n][P0][C0][2] (+ s1 for the 2nd concat source)
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ s0, int P0, int C0,
-                                                          const float* __restrict__ s1, int P1, int C1,
-                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          const float* __restrict__ film, int film_ld, float* __restrict__ ca,
-                                                          float* __restrict__ cb, int HW, int G, float eps) {
-  __shared__ double red[2][4];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, n = blockIdx.x, g = blockIdx.y;
-  const int C = C0 + C1, cpg = C / G;
-  double s = 0.0, q = 0.0;
-  if (cpg <= 256) {
-    // thread = (partial row, channel of the group): the group's cpg (sum, sumsq) pairs of a row are contiguous, so a wave
-    // reads whole 8*cpg-byte runs instead of one strided pair per thread
-    const int j = tid % cpg, plane = tid / cpg, pstep = 256 / cpg;
-    if (plane < pstep) {
-      const int c = g * cpg + j;
-      const bool second = c >= C0;
-      const float* src = second ? s1 + ((int64_t)n * P1 * C1 + (c - C0)) * 2 : s0 + ((int64_t)n * P0 * C0 + c) * 2;
-      const int P = second ? P1 : P0, ld = (second ? C1 : C0) * 2;
-      float fs = 0.f, fq = 0.f;
-      int cnt = 0;
-      for (int p = plane; p < P; p += pstep) {
-        const float2 v = *(const float2*)(src + (int64_t)p * ld);
-        fs += v.x; fq += v.y;
-        if (++cnt == 64) { s += fs; q += fq; fs = fq = 0.f; cnt = 0; }   // short fp32 runs, double across them
-      }
-      s += fs; q += fq;
-    }
-  } else {
-    for (int j = 0; j < cpg; ++j) {
-      const int c = g * cpg + j;
-      const bool second = c >= C0;
-      const float* src = second ? s1 + ((int64_t)n * P1 * C1 + (c - C0)) * 2 : s0 + ((int64_t)n * P0 * C0 + c) * 2;
-      const int P = second ? P1 : P0, ld = (second ? C1 : C0) * 2;
-      for (int p = tid; p < P; p += 256) { s += src[(int64_t)p * ld]; q += src[(int64_t)p * ld + 1]; }
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-  if (lane == 0) { red[0][wid] = s; red[1][wid] = q; }
-  __syncthreads();
-  s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-  q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+// One workgroup per (sample, group, slice).  Partials are per channel: s0[n][P0][C0][2] (+ s1 for the 2nd concat source); the
+// group's (sum, sumsq) pairs of a partial row are contiguous, so the reduction is a flat coalesced walk.  With gridDim.z == 1
+// the workgroup writes the coefficients itself.  With few (sample, group) pairs -- GroupNorm(1, C) of the v-diffusion nets at
+// batch 1 is ONE pair -- the rows are split over gridDim.z slices that each leave a (sum, sumsq) pair of doubles in the
+// group's own slots of coef_b, and gn_finalize2_kernel adds them in order (a single workgroup took 120 us per call there:
+// 16 of the 23 ms of a cc12m_1 step).
+__device__ __forceinline__ void gn_coeffs_out(double s, double q, int n, int g, int C, int cpg, int HW, float eps,
+                                              const float* gamma, const float* beta, const float* film, int film_ld,
+                                              float* ca, float* cb, int tid) {
   const double cnt = (double)HW * cpg;
   const double mean = s / cnt;
   double var = q / cnt - mean * mean;
@@ -106,6 +72,64 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
     ca[(int64_t)n * C + c] = a; cb[(int64_t)n * C + c] = b;
   }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ s0, int P0, int C0,
+                                                          const float* __restrict__ s1, int P1, int C1,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ film, int film_ld, float* __restrict__ ca,
+                                                          float* __restrict__ cb, int HW, int G, float eps) {
+  __shared__ double red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, n = blockIdx.x, g = blockIdx.y;
+  const int slice = blockIdx.z, S = gridDim.z;
+  const int C = C0 + C1, cpg = C / G;
+  double s = 0.0, q = 0.0;
+  auto walk = [&](const float* base, int P, int Csrc, int c_lo, int c_hi) {     // channels [c_lo, c_hi) of one source
+    const int w = c_hi - c_lo;
+    if (w <= 0) return;
+    const int64_t total = (int64_t)P * w;
+    float fs = 0.f, fq = 0.f;
+    int cnt = 0;
+    for (int64_t i = (int64_t)slice * 256 + tid; i < total; i += (int64_t)S * 256) {
+      const int pr = (int)(i / w), j = (int)(i - (int64_t)pr * w);
+      const float2 v = *(const float2*)(base + ((int64_t)pr * Csrc + c_lo + j) * 2);
+      fs += v.x; fq += v.y;
+      if (++cnt == 64) { s += fs; q += fq; fs = fq = 0.f; cnt = 0; }   // short fp32 runs, double across them
+    }
+    s += fs; q += fq;
+  };
+  const int g_lo = g * cpg, g_hi = g_lo + cpg;
+  walk(s0 + (int64_t)n * P0 * C0 * 2, P0, C0, min(g_lo, C0), min(g_hi, C0));
+  if (s1) walk(s1 + (int64_t)n * P1 * C1 * 2, P1, C1, max(g_lo, C0) - C0, max(g_hi, C0) - C0);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+  if (lane == 0) { red[0][wid] = s; red[1][wid] = q; }
+  __syncthreads();
+  s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  if (S > 1) {
+    if (tid == 0) {
+      double* part = (double*)(cb + (int64_t)n * C + g_lo) + 2 * slice;
+      part[0] = s; part[1] = q;
+    }
+    return;
+  }
+  gn_coeffs_out(s, q, n, g, C, cpg, HW, eps, gamma, beta, film, film_ld, ca, cb, tid);
+}
+
+__global__ __launch_bounds__(256) void gn_finalize2_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ film, int film_ld, float* __restrict__ ca,
+                                                           float* __restrict__ cb, int C, int HW, int G, int S, float eps) {
+  __shared__ double tot[2];
+  const int tid = threadIdx.x, n = blockIdx.x, g = blockIdx.y, cpg = C / G;
+  if (tid == 0) {
+    const double* part = (const double*)(cb + (int64_t)n * C + g * cpg);
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < S; ++i) { s += part[2 * i]; q += part[2 * i + 1]; }     // fixed order
+    tot[0] = s; tot[1] = q;
+  }
+  __syncthreads();       // the partials are consumed before the coefficients overwrite their slots
+  gn_coeffs_out(tot[0], tot[1], n, g, C, cpg, HW, eps, gamma, beta, film, film_ld, ca, cb, tid);
 }
 
 template <typename T>
@@ -183,9 +207,23 @@ extern "C" int pmi_gn_finalize(const float* s0, int P0, int C0, const float* s1,
   if (!s1) { C1 = 0; P1 = 0; }
   const int C = C0 + C1;
   if (!s0 || !coef_a || !coef_b || N <= 0 || C0 <= 0 || P0 <= 0 || G <= 0 || C % G || (s1 && P1 <= 0)) return PMI_ERR_ARG;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N, G), dim3(256), 0, (hipStream_t)s, s0, P0, C0, s1, P1, C1, gamma, beta, film, film_ld,
+  // few (sample, group) pairs and many partial rows: split the rows over S slices (each needs 16 bytes inside the group's cpg floats)
+  const int cpg = C / G;
+  int S = 1;
+  const int64_t work = (int64_t)(P0 > P1 ? P0 : P1) * cpg;
+  if (N * G < 128 && work >= 32768 && (cpg & 1) == 0) {
+    S = 256 / (N * G);
+    if (S > cpg / 4) S = cpg / 4;
+    if (S > 64) S = 64;
+    if (S < 2) S = 1;
+  }
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N, G, S), dim3(256), 0, (hipStream_t)s, s0, P0, C0, s1, P1, C1, gamma, beta, film, film_ld,
                      coef_a, coef_b, HW, G, eps);
   PMI_CHECK_LAUNCH();
+  if (S > 1) {
+    hipLaunchKernelGGL(gn_finalize2_kernel, dim3(N, G), dim3(256), 0, (hipStream_t)s, gamma, beta, film, film_ld, coef_a, coef_b, C, HW, G, S, eps);
+    PMI_CHECK_LAUNCH();
+  }
   return PMI_OK;
 }
 
