@@ -75,3 +75,31 @@ def test_full_size_clip_guidance_gradient_shards_exactly(workload):
         assert float(cos) >= 0.9999
     guided = model.predictions(images, sched[3][0]).guided(grad, guidance_scale=0.5, clamp_value=1e-6)
     assert bool(torch.isfinite(guided.predicted_noise).all())
+
+
+def test_graph_replay_of_a_guided_step_matches_eager_bit_for_bit():
+    """engine/graph.py: the whole step (UNet -> CLIP gradient -> guidance -> DDIM) captured into a HIP graph, small config."""
+    from perceptor_amd import losses, models
+    from perceptor_amd.engine.graph import GraphedStep
+    from perceptor_amd.utils.synth import seeded_noise
+    dev = torch.device("cuda:0")
+    model = models.VelocityDiffusion("cc12m_1_cfg", dtype="bf16").to(dev)
+    clip = losses.OpenCLIP("ViT-B-32", "synthetic", dtype="bf16").to(dev)
+    clip.add_encodings_(torch.nn.functional.normalize(seeded_noise((2, clip.model.output_dim), 7)).to(dev))
+    cond = seeded_noise((1, 1, 512), 11).to(dev)
+    images = (seeded_noise((1, 3, 128, 128), 5) * 0.5 + 0.5).to(dev)
+    sched = model.schedule_ts(n_steps=8).to(dev)
+
+    def step(img, t_from, t_to):
+        pred = model.predictions(img, t_from, cond)
+        _, grad = clip.loss_and_grad(pred.denoised_images, n_total=1)
+        return pred.guided(grad, guidance_scale=0.5, clamp_value=1e-6).step(t_to)
+
+    eager = images
+    for i in range(3):
+        eager = step(eager, sched[i][0], sched[i][1])
+    g = GraphedStep(step, images, sched[0][0], sched[0][1])
+    replay = images
+    for i in range(3):
+        replay = g(replay, sched[i][0], sched[i][1]).clone()
+    assert torch.equal(replay, eager)
