@@ -68,7 +68,8 @@ typedef struct {
   int32_t reserved;
 } pmi_igemm_args;
 int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream);
-/* >= 0 when the LDS-halo conv3x3 kernel (csrc/conv3x3.hip) takes this shape (tile config 0: 8x32 px x 256 ch, 1: 16x32 x 128, 2: 8x32 x 128),
+/* >= 0 when the LDS-halo conv3x3 kernel (csrc/conv3x3.hip) takes this shape (tile config 0: 8x32 px x 256 ch, 1: 16x32 x 128, 2: 8x32 x 128 with two workgroups per CU -- the default,
+ * 3: 8x32 px x <= 32 output channels),
  * -1 when pmi_igemm uses the generic implicit-GEMM kernel (which has no fused prologue). */
 int pmi_conv3x3_halo_config(const pmi_igemm_args* a);
 /* split-K factor recommended for this shape (1 = none); with splitk = S the caller passes ws = S*M*N floats */
