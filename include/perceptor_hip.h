@@ -78,7 +78,8 @@ int pmi_igemm_splitk(const pmi_igemm_args* a);
 int pmi_igemm_stats_rows(const pmi_igemm_args* a);
 /* debugging / A-B switches: key 0 = allow the LDS-halo conv3x3 kernel (default 1, returns the previous value);
  * key 1 = force halo tile config 0/1/2 where eligible (-1 = automatic);
- * key 4 = route plain GEMMs (one source, no convolution gather, no fused activation / statistics) to hipBLASLt (default 1). */
+ * key 4 = route plain GEMMs (one source, no convolution gather, no fused activation / statistics) to hipBLASLt (default 1);
+ * key 5 = percent by which a hipBLASLt candidate must beat the heuristic's first pick to replace it when a shape is first timed (default 8). */
 int pmi_set_option(int key, int value);
 
 /* ---- GroupNorm (+FiLM, +activation, +2x2 average pool) ---------------------------

@@ -30,6 +30,7 @@ hipblasLtHandle_t g_handle = nullptr;
 void* g_ws = nullptr;
 constexpr size_t WS_BYTES = 64u << 20;
 int g_enabled = 1, g_tune = 1;
+float g_margin = 0.92f;
 
 bool eligible(const pmi_igemm_args& a) {
   if (!g_enabled) return false;
@@ -79,6 +80,7 @@ Plan& plan_for(const pmi_igemm_args& a) {
 }  // namespace
 
 void pmi_gemm_lt_enable(int v) { g_enabled = v; }
+void pmi_gemm_lt_margin(int percent) { g_margin = 1.f - 0.01f * (float)percent; }
 int pmi_gemm_lt_eligible(const pmi_igemm_args* a) { return eligible(*a) ? 1 : 0; }
 
 // PMI_OK when the library ran the GEMM, 1 when the caller should use the generic kernel instead
@@ -108,7 +110,7 @@ int pmi_gemm_lt(const pmi_igemm_args* a, void* stream) {
     if (hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
       hipEvent_t e0, e1;
       (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-      float best_ms = 1e30f;
+      float best_ms = 1e30f, first_ms = 0.f;
       for (int i = 0; i < p.nalgo; ++i) {
         if (run(i) != HIPBLAS_STATUS_SUCCESS) continue;          // warm-up (code object load)
         (void)hipEventRecord(e0, s);
@@ -118,7 +120,9 @@ int pmi_gemm_lt(const pmi_igemm_args* a, void* stream) {
         (void)hipEventSynchronize(e1);
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
-        if (good && ms < best_ms) { best_ms = ms; p.best = i; }
+        if (i == 0) first_ms = good ? ms : 1e30f;
+        // leave the heuristic's first pick unless a candidate is clearly (8 %) faster: near-ties must not flip between processes
+        if (good && ms < best_ms && (i == 0 || ms < g_margin * first_ms)) { best_ms = ms; p.best = i; }
       }
       (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
       p.tuned = true;

@@ -423,6 +423,7 @@ int pmi_conv3x3_halo_launch(const pmi_igemm_args* a, int cfg, void* stream);
 int pmi_gemm_lt(const pmi_igemm_args* a, void* stream);          // gemm_lt.hip: 0 = done by hipBLASLt, 1 = use the generic kernel
 int pmi_gemm_lt_eligible(const pmi_igemm_args* a);
 void pmi_gemm_lt_enable(int v);
+void pmi_gemm_lt_margin(int percent);
 void pmi_conv3x3_force_config(int cfg);
 void pmi_conv3x3_use_glds(int v);
 void pmi_conv3x3_persistent(int v);
@@ -457,6 +458,7 @@ extern "C" int pmi_set_option(int key, int value) {
   if (key == 2) { pmi_conv3x3_use_glds(value); return 0; }
   if (key == 3) { pmi_conv3x3_persistent(value); return 0; }
   if (key == 4) { pmi_gemm_lt_enable(value); return 0; }
+  if (key == 5) { pmi_gemm_lt_margin(value); return 0; }
   return PMI_ERR_ARG;
 }
 
