@@ -68,7 +68,7 @@ typedef struct {
   int32_t reserved;
 } pmi_igemm_args;
 int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream);
-/* >= 0 when the LDS-halo conv3x3 kernel (csrc/conv3x3.hip) takes this shape (tile config 0: 8x32 px x 256 ch, 1: 16x32 x 128, 2: 8x32 x 128 with two workgroups per CU -- the default,
+/* >= 0 when the LDS-halo conv3x3 kernel (csrc/conv3x3.hip) takes this shape (tile config 0: 8x32 px x 256 ch, 1: 16x32 x 128, 2: 8x32 x 128 with two workgroups per CU,
  * 3: 8x32 px x <= 32 output channels),
  * -1 when pmi_igemm uses the generic implicit-GEMM kernel (which has no fused prologue). */
 int pmi_conv3x3_halo_config(const pmi_igemm_args* a);
@@ -78,6 +78,7 @@ int pmi_igemm_splitk(const pmi_igemm_args* a);
 int pmi_igemm_stats_rows(const pmi_igemm_args* a);
 /* debugging / A-B switches: key 0 = allow the LDS-halo conv3x3 kernel (default 1, returns the previous value);
  * key 1 = force halo tile config 0/1/2 where eligible (-1 = automatic);
+ * key 2 = prefer the 8-wave 256-channel halo config over two 4-wave workgroups per CU where the grid allows (default 1);
  * key 4 = route plain GEMMs (one source, no convolution gather, no fused activation / statistics) to hipBLASLt (default 1);
  * key 5 = percent by which a hipBLASLt candidate must beat the heuristic's first pick to replace it when a shape is first timed (default 8). */
 int pmi_set_option(int key, int value);

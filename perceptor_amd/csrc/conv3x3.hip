@@ -151,6 +151,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // MFMAs of one tap; the next tap's weights (already travelling global -> registers) are written to the other LDS buffer
+  // after the third of the four 16-channel steps, so their ds_write latency hides under the last step's MFMAs and only the
+  // barrier itself remains at the end of the tap (+2-9 % over storing after the last step; after the second step: less).
   auto mma_tap = [&](int tap, int cur) {
     const int dy = tap / 3, dx = tap - dy * 3;          // patch row/col offset (tap - 1 + halo 1)
     const char* wb = wbuf + cur * WBYTES;
@@ -166,6 +169,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
       for (int i = 0; i < XB; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma32(wf[j], xf[i], acc[i][j]);
+      if (kk == 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        store_w(cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
 
@@ -178,14 +186,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
   STAMP(1);
   int cur = 0;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
-    // taps 0..7: the next tap's weights travel global -> registers under this tap's MFMAs, then registers -> the other buffer
+    // taps 0..7: the next tap's weights travel global -> registers -> the other LDS buffer under this tap's MFMAs
 #pragma unroll 1
     for (int tap = 0; tap < 8; ++tap) {
       load_w(chunk, tap + 1);
       __builtin_amdgcn_sched_barrier(0);   // keep the loads in front of the MFMAs (the scheduler sinks them to their use)
       mma_tap(tap, cur);
-      __builtin_amdgcn_sched_barrier(0);
-      store_w(cur ^ 1);
       __syncthreads();
       cur ^= 1;
     }
@@ -197,8 +203,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
     if (EARLY && more) load_patch(chunk + 1);
     __builtin_amdgcn_sched_barrier(0);
     mma_tap(8, cur);
-    __builtin_amdgcn_sched_barrier(0);
-    store_w(cur ^ 1);
     if (more) {
       if (!EARLY) load_patch(chunk + 1);
       __syncthreads();          // every wave is done reading the current patch
@@ -400,9 +404,10 @@ int launch_t(const pmi_igemm_args& a, hipStream_t s, int cfg) {
 }  // namespace
 
 // Returns the config the halo kernel can run (0: 8x32 x 256ch, 1: 16x32 x 128ch) or -1 if the shape needs the generic kernel.
+static int g_prefer0 = 1;      // pmi_set_option(2, v): prefer the 8-wave 256-channel config where the grid allows (A/B)
 static int g_force_cfg = -1;   // pmi_set_option(1, cfg): force a tile config where eligible (A/B benchmarking)
 void pmi_conv3x3_force_config(int cfg) { g_force_cfg = cfg; }
-void pmi_conv3x3_use_glds(int) {}      // experiments measured and dropped: direct-to-LDS weights, persistent tiles, start stagger
+void pmi_conv3x3_use_glds(int v) { g_prefer0 = v; }      // experiments measured and dropped: direct-to-LDS weights, persistent tiles, start stagger
 void pmi_conv3x3_persistent(int) {}    // incremental patch staging: measured (876 vs 943 TFLOP/s) and dropped
 
 // Returns the tile config the halo kernel runs for this shape (0: 8x32 px x 256 ch / 8 waves, 1: 16x32 x 128 / 8 waves,
@@ -422,9 +427,11 @@ extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
   // at batch 8) go to the generic kernel, whose 128x128 tiles (and split-K) fill the chip.
   const int nimg = a->M / (a->H * a->W);
   const int px_tiles8 = nimg * (a->H / 8) * (a->W / 32);
-  // Two 4-wave workgroups per CU (cfg 2) beat one 8-wave workgroup (cfg 0/1) by 5-9 % on every UNet shape measured:
-  // all workgroups of a launch run in lockstep, so the epilogues of all 256 CUs hit HBM at once (11-20 us of a 60-100 us
-  // tile, measured with in-kernel timestamps); with two workgroups per CU one computes while the other drains.
+  // Measured per shape (tools/conv_sweep.sh).  Two 4-wave workgroups per CU (cfg 2) hide each workgroup's prologue / epilogue
+  // behind the other's main loop: all workgroups of a launch run in lockstep, so with one workgroup per CU every epilogue hits
+  // HBM at the same moment.  With 256-channel tiles one 8-wave workgroup per CU (cfg 0: the patch is staged once for 256
+  // output channels) is 3-12 % ahead again since the weight stores moved under the MFMAs.
+  if (g_prefer0 && (a->N % 256) == 0 && px_tiles8 * (a->N / 256) >= 256) return 0;
   if (px_tiles8 * (a->N / 128) >= 384) return 2;
   if ((a->N % 256) == 0) return px_tiles8 * (a->N / 256) >= 192 ? 0 : -1;
   if (ok1 && (px_tiles8 / 2) * (a->N / 128) >= 192) return 1;
