@@ -30,7 +30,10 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((ch
 // loads in flight at every branch join and fell back to s_waitcnt vmcnt(0) -- right after issuing the next tap's weight
 // loads, i.e. one exposed L2 round trip per tap in front of the MFMAs.
 // NJ: 32-channel MFMA blocks per wave (4 = 128 output channels; 1 for convs with <= 32 output channels, e.g. the UNet's last conv).
-template <typename T, int WM, int WN, int PRO, bool EARLY, int NJ = 4>
+// NWB: weight buffers in LDS.  2: write the next tap's weights after the third k-step, barrier at the end of the tap.  3 (one
+// workgroup per CU, LDS permitting): the buffer being written was last read two taps ago, so the only barrier of a tap sits
+// right behind the weight stores and the last k-step plus the next tap's first fragment reads run without a stop.
+template <typename T, int WM, int WN, int PRO, bool EARLY, int NJ = 4, int NWB = 2>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi_igemm_args a) {
   constexpr int XB = 2;                                // image rows (32-pixel MFMA blocks) per wave
   constexpr int TH = WM * XB;                          // image rows per tile
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
   constexpr int NWI = BN / RPI;                        // 16-byte weight chunks per thread per tap
   constexpr int PATCH_BYTES = NPI * RPI * 128;         // padded to whole staging passes: no bounds test on the LDS writes
   constexpr int WBYTES = BN * 128;
-  __shared__ __attribute__((aligned(16))) char smem[PATCH_BYTES + 2 * WBYTES];
+  __shared__ __attribute__((aligned(16))) char smem[PATCH_BYTES + NWB * WBYTES];
   char* const wbuf = smem + PATCH_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
   // MFMAs of one tap; the next tap's weights (already travelling global -> registers) are written to the other LDS buffer
   // after the third of the four 16-channel steps, so their ds_write latency hides under the last step's MFMAs and only the
   // barrier itself remains at the end of the tap (+2-9 % over storing after the last step; after the second step: less).
-  auto mma_tap = [&](int tap, int cur) {
+  auto mma_tap = [&](int tap, int cur, int nxt) {
     const int dy = tap / 3, dx = tap - dy * 3;          // patch row/col offset (tap - 1 + halo 1)
     const char* wb = wbuf + cur * WBYTES;
 #pragma unroll
@@ -171,7 +174,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
         for (int j = 0; j < NJ; ++j) acc[i][j] = T::mfma32(wf[j], xf[i], acc[i][j]);
       if (kk == 2) {
         __builtin_amdgcn_sched_barrier(0);
-        store_w(cur ^ 1);
+        store_w(nxt);
+        if (NWB == 3) __syncthreads();     // publishes the next tap's weights; nobody is reading buffer nxt (last used two taps ago)
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -191,9 +195,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
     for (int tap = 0; tap < 8; ++tap) {
       load_w(chunk, tap + 1);
       __builtin_amdgcn_sched_barrier(0);   // keep the loads in front of the MFMAs (the scheduler sinks them to their use)
-      mma_tap(tap, cur);
-      __syncthreads();
-      cur ^= 1;
+      const int nxt = NWB == 3 ? (cur == 2 ? 0 : cur + 1) : cur ^ 1;
+      mma_tap(tap, cur, nxt);
+      if (NWB == 2) __syncthreads();
+      cur = nxt;
     }
     // tap 8 also brings in the next 64-channel patch.  Without a prologue it is prefetched into registers under the MFMAs;
     // with the fused GroupNorm prologue that would exceed 256 VGPRs, so it is loaded after them (the second workgroup
@@ -202,14 +207,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
     load_w(more ? chunk + 1 : 0, 0);
     if (EARLY && more) load_patch(chunk + 1);
     __builtin_amdgcn_sched_barrier(0);
-    mma_tap(8, cur);
+    const int nxt8 = NWB == 3 ? (cur == 2 ? 0 : cur + 1) : cur ^ 1;
+    mma_tap(8, cur, nxt8);
     if (more) {
       if (!EARLY) load_patch(chunk + 1);
       __syncthreads();          // every wave is done reading the current patch
       store_patch();
     }
     __syncthreads();
-    cur ^= 1;
+    cur = nxt8;
   }
 
   STAMP(2);
@@ -375,7 +381,7 @@ int launch_p(const pmi_igemm_args& a, hipStream_t s, int cfg) {
   const int nimg = a.M / (a.H * a.W);
   if (cfg == 0) {          // 8x32 px x 256 ch, 8 waves, one workgroup per CU
     const int tiles = nimg * (a.H / 8) * (a.W / 32) * ((a.N + 255) / 256);
-    hipLaunchKernelGGL((conv3x3_halo_kernel<T, 4, 2, PRO, PRO == 0>), dim3(tiles), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<T, 4, 2, PRO, PRO == 0, 4, 3>), dim3(tiles), dim3(512), 0, s, a);
   } else if (cfg == 1) {   // 16x32 px x 128 ch, 8 waves
     const int tiles = nimg * (a.H / 16) * (a.W / 32) * ((a.N + 127) / 128);
     hipLaunchKernelGGL((conv3x3_halo_kernel<T, 8, 1, PRO, PRO == 0>), dim3(tiles), dim3(512), 0, s, a);
