@@ -438,7 +438,7 @@ extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
   // HBM at the same moment.  With 256-channel tiles one 8-wave workgroup per CU (cfg 0: the patch is staged once for 256
   // output channels) is 3-12 % ahead again since the weight stores moved under the MFMAs.
   if (g_prefer0 && (a->N % 256) == 0 && px_tiles8 * (a->N / 256) >= 256) return 0;
-  if (px_tiles8 * (a->N / 128) >= 384) return 2;
+  if (px_tiles8 * (a->N / 128) >= 128) return 2;      // even at one workgroup per two CUs the fused prologue / statistics beat the generic path
   if ((a->N % 256) == 0) return px_tiles8 * (a->N / 256) >= 192 ? 0 : -1;
   if (ok1 && (px_tiles8 / 2) * (a->N / 128) >= 192) return 1;
   return -1;
