@@ -203,11 +203,13 @@ class VDiffEngine:
                 return ops.igemm(h, w[p + ".c2"], residual=skip, out_f32=True)
             return ops.igemm(h, w[p + ".c2"], act=ACT_RELU, residual=skip)
         ld = mod.stride(0)
-        h = ops.igemm(x, w[p + ".c1"], a1=x1)
-        h = ops.group_norm(h, None, None, 1, dt, film=mod[:, l.mod1:], film_ld=ld, act=ACT_RELU)
+        # conv1 leaves the statistics of its output behind; GroupNorm(1, C) + Modulation2d + ReLU are applied by conv2 while it
+        # stages its input (no normalised copy in HBM); where a shape is not eligible ops.igemm falls back to the streaming kernels
+        h = ops.igemm(x, w[p + ".c1"], a1=x1, want_stats=True)
+        ca, cb = ops.group_norm_coeffs(h, None, None, 1, dt, film=mod[:, l.mod1:], film_ld=ld)
         if l.last:
-            return ops.igemm(h, w[p + ".c2"], residual=skip, out_f32=True)
-        h = ops.igemm(h, w[p + ".c2"])
+            return ops.igemm(h, w[p + ".c2"], residual=skip, out_f32=True, prologue=(ca, cb, ACT_RELU))
+        h = ops.igemm(h, w[p + ".c2"], prologue=(ca, cb, ACT_RELU), want_stats=True)
         return ops.group_norm(h, None, None, 1, dt, film=mod[:, l.mod2:], film_ld=ld, act=ACT_RELU, residual=skip)
 
     def _attn(self, l: Attn, p, x):
