@@ -35,15 +35,28 @@ def _worker(rank, world, port, n_total, q):
 def test_two_rank_sharding_matches_single_process(n_total):
     from perceptor_amd.utils.synth import seeded_noise
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    out = dict(q.get(timeout=120) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+
+    def attempt():
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        try:
+            out = dict(q.get(timeout=180) for _ in range(2))
+            for p in procs:
+                p.join(timeout=120)
+            return out if all(p.exitcode == 0 for p in procs) else None
+        except Exception:
+            return None
+        finally:
+            for p in procs:
+                if p.is_alive():
+                    p.kill()          # exact child processes started above
+
+    # the port found by _free_port() can be taken by another process before the ranks bind it: one retry with a new port
+    out = attempt() or attempt()
+    assert out is not None, "the two gloo ranks did not finish"
     ref = seeded_noise((n_total, 3, 8, 8), 1234) * 0.5 + 0.5
     assert torch.equal(out[0], ref) and torch.equal(out[1], ref)
 
