@@ -24,6 +24,8 @@ def env_world() -> Tuple[int, int, int]:
 def init(backend: str = "nccl"):
     import torch.distributed as dist
     rank, local_rank, world = env_world()
+    if backend == "nccl" and torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)        # one process per GPU; RCCL binds its communicator to the current device
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
