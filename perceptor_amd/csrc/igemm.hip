@@ -248,6 +248,68 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
   }
   // ---- epilogue: lane = pixel (col), registers = 4 consecutive output channels x 4 groups ----
   float* const stat = (float*)smem;            // [2 wave rows][BN][2] per-channel (sum, sumsq) of this tile (main loop is done with LDS)
+  // Fast path (16-bit output, 16-byte aligned rows, no statistics): each wave transposes its 64 x 64 tile through LDS and writes
+  // 16 bytes per lane, 8 rows x 128 B per instruction, reading a 16-bit residual the same way.  In the accumulator layout a
+  // store instruction covers 32 rows x 16 bytes, which the address coalescer handles several times slower -- decisive for the
+  // short-K, store-heavy 1x1 convolutions (M = 2M rows, K = 256..768).
+  const bool fast = !a.out_f32 && !a.stats && !a.res_up && (a.ldd & 7) == 0 && (offD & 7) == 0 && (a.N & 7) == 0 && (((uintptr_t)a.D) & 15) == 0 &&
+                    (!a.R || (!a.res_f32 && (a.ldr & 7) == 0 && (offR & 7) == 0 && (((uintptr_t)a.R) & 15) == 0));
+  if (fast) {
+    constexpr int SROW = 144;                  // staged row: 128 B + 16 B pad
+    char* const stg = smem + wid * (64 * SROW);
+    const int r8 = lane & 7, rp = lane >> 3;   // write-out role: 16-byte chunk r8 of row 8 t + rp
+    const float* nbq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + wr * 64 + i * 32 + l31;
+      nbq[i] = (a.nbias && m < a.M) ? a.nbias + (int64_t)(m / a.hw) * (a.ldnb ? a.ldnb : a.N) : nullptr;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wc * 64 + j * 32 + 4 * lhi + 8 * g;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias && n < a.N) b = *(const float4*)(a.bias + n);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float v[4] = {acc[i][j][4 * g] * a.alpha + b.x, acc[i][j][4 * g + 1] * a.alpha + b.y,
+                        acc[i][j][4 * g + 2] * a.alpha + b.z, acc[i][j][4 * g + 3] * a.alpha + b.w};
+          if (nbq[i] && n < a.N) { const float4 q = *(const float4*)(nbq[i] + n); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
+          if (a.act != PMI_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
+          }
+          *(uint2*)(stg + (i * 32 + l31) * SROW + (j * 32 + 8 * g + 4 * lhi) * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);       // one 32-column block of bias loads in flight at a time (register budget)
+    }
+    const int cl0 = wc * 64 + r8 * 8;          // first of this lane's 8 columns inside the tile
+    const bool nok = n0 + cl0 < a.N;
+    uint4 rres[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int m = m0 + wr * 64 + 8 * t + rp;
+      rres[t] = make_uint4(0, 0, 0, 0);
+      if (a.R && nok && m < a.M) rres[t] = *(const uint4*)((const u16*)a.R + offR + (int64_t)m * a.ldr + n0 + cl0);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int m = m0 + wr * 64 + 8 * t + rp;
+      uint4 v = *(const uint4*)(stg + (8 * t + rp) * SROW + r8 * 16);
+      if (a.R) {
+        float f[8], r[8];
+        unpack8<T>(v, f);
+        unpack8<T>(rres[t], r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += r[e];
+        v = pack8<T>(f);
+      }
+      if (nok && m < a.M) *(uint4*)((u16*)a.D + offD + (int64_t)m * a.ldd + n0 + cl0) = v;
+    }
+    return;
+  }
   int64_t rrow[2];
   const float* nbp[2];
   int mrow[2];
