@@ -248,15 +248,15 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
   }
   // ---- epilogue: lane = pixel (col), registers = 4 consecutive output channels x 4 groups ----
   float* const stat = (float*)smem;            // [2 wave rows][BN][2] per-channel (sum, sumsq) of this tile (main loop is done with LDS)
-  // Fast path (16-bit output, 16-byte aligned rows, no statistics): each wave transposes its 64 x 64 tile through LDS and writes
+  // Fast path (16-bit output, 16-byte aligned rows): each wave transposes its 64 x 64 tile through LDS and writes
   // 16 bytes per lane, 8 rows x 128 B per instruction, reading a 16-bit residual the same way.  In the accumulator layout a
   // store instruction covers 32 rows x 16 bytes, which the address coalescer handles several times slower -- decisive for the
   // short-K, store-heavy 1x1 convolutions (M = 2M rows, K = 256..768).
-  const bool fast = !a.out_f32 && !a.stats && !a.res_up && (a.ldd & 7) == 0 && (offD & 7) == 0 && (a.N & 7) == 0 && (((uintptr_t)a.D) & 15) == 0 &&
+  const bool fast = !a.out_f32 && !a.res_up && (a.ldd & 7) == 0 && (offD & 7) == 0 && (a.N & 7) == 0 && (((uintptr_t)a.D) & 15) == 0 &&
                     (!a.R || (!a.res_f32 && (a.ldr & 7) == 0 && (offR & 7) == 0 && (((uintptr_t)a.R) & 15) == 0));
   if (fast) {
     constexpr int SROW = 144;                  // staged row: 128 B + 16 B pad
-    char* const stg = smem + wid * (64 * SROW);
+    char* const stg = smem + 2 * 2 * BN * 4 + wid * (64 * SROW);      // behind the two statistics slots
     const int r8 = lane & 7, rp = lane >> 3;   // write-out role: 16-byte chunk r8 of row 8 t + rp
     const float* nbq[2];
 #pragma unroll
@@ -294,22 +294,45 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
       rres[t] = make_uint4(0, 0, 0, 0);
       if (a.R && nok && m < a.M) rres[t] = *(const uint4*)((const u16*)a.R + offR + (int64_t)m * a.ldr + n0 + cl0);
     }
+    float cs[16];                              // [0..7] sums, [8..15] sums of squares of this lane's 8 columns
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cs[e] = 0.f;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int m = m0 + wr * 64 + 8 * t + rp;
       uint4 v = *(const uint4*)(stg + (8 * t + rp) * SROW + r8 * 16);
-      if (a.R) {
-        float f[8], r[8];
+      if (a.R || a.stats) {
+        float f[8];
         unpack8<T>(v, f);
-        unpack8<T>(rres[t], r);
+        if (a.R) {
+          float r[8];
+          unpack8<T>(rres[t], r);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] += r[e];
-        v = pack8<T>(f);
+          for (int e = 0; e < 8; ++e) f[e] += r[e];
+          v = pack8<T>(f);
+        }
+        if (m < a.M) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { cs[e] += f[e]; cs[8 + e] += f[e] * f[e]; }
+        }
       }
       if (nok && m < a.M) *(uint4*)((u16*)a.D + offD + (int64_t)m * a.ldd + n0 + cl0) = v;
     }
-    return;
-  }
+    if (a.stats) {   // butterfly over the 8 lanes that share r8 (lane bits 3..5), halving the live values per step; one slot per wave row
+      float b8[8], b4[4], b2[2];
+      const bool h3 = lane & 8, h4 = lane & 16, h5 = lane & 32;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float mine = h3 ? cs[k + 8] : cs[k], other = h3 ? cs[k] : cs[k + 8]; b8[k] = mine + __shfl_xor(other, 8); }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float mine = h4 ? b8[k + 4] : b8[k], other = h4 ? b8[k] : b8[k + 4]; b4[k] = mine + __shfl_xor(other, 16); }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) { const float mine = h5 ? b4[k + 2] : b4[k], other = h5 ? b4[k] : b4[k + 2]; b2[k] = mine + __shfl_xor(other, 32); }
+      const int e0 = (h4 ? 4 : 0) + (h5 ? 2 : 0);
+      float* const slot = stat + wr * 2 * BN;
+      slot[2 * (cl0 + e0) + (h3 ? 1 : 0)] = b2[0];
+      slot[2 * (cl0 + e0 + 1) + (h3 ? 1 : 0)] = b2[1];
+    }
+  } else {
   int64_t rrow[2];
   const float* nbp[2];
   int mrow[2];
@@ -394,6 +417,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
       }
     }
     if (a.stats) stats_block_to_lds(ssum, ssq, stat + wr * 2 * BN, wc * 64 + j * 32, lane);
+  }
   }
   if (a.stats) {
     __syncthreads();
