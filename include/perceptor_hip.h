@@ -66,10 +66,12 @@ typedef struct {
   int32_t stats_p;     /* partial rows per image = pmi_igemm_stats_rows(); 0 = no statistics */
   int32_t splitk;      /* <= 1: none; else K is split over grid.z and reduced by a second kernel (see pmi_igemm_splitk) */
   int32_t reserved;
+  const void* Bf;      /* optional: the same weights in MFMA fragment order for the weights-direct conv3x3 kernel (csrc/conv_wd.hip),
+                        * [N/32][Cin/ck][3 dx][ck/16][3 dy][64 lanes][8] 16-bit with ck = 64 (tile config 4) or 32 (config 5); NULL = not packed */
 } pmi_igemm_args;
 int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream);
-/* >= 0 when the LDS-halo conv3x3 kernel (csrc/conv3x3.hip) takes this shape (tile config 0: 8x32 px x 256 ch, 1: 16x32 x 128, 2: 8x32 x 128 with two workgroups per CU,
- * 3: 8x32 px x <= 32 output channels),
+/* >= 0 when an LDS-halo conv3x3 kernel takes this shape.  csrc/conv3x3.hip: tile config 0: 8x32 px x 256 ch, 1: 16x32 x 128, 2: 8x32 x 128 with two
+ * workgroups per CU, 3: 8x32 px x <= 32 output channels; csrc/conv_wd.hip (weights-direct, needs Bf != NULL): 4: 8x32 px x 256 ch, 5: 8x32 px x 128 ch;
  * -1 when pmi_igemm uses the generic implicit-GEMM kernel (which has no fused prologue). */
 int pmi_conv3x3_halo_config(const pmi_igemm_args* a);
 /* split-K factor recommended for this shape (1 = none); with splitk = S the caller passes ws = S*M*N floats */

@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libperceptor_hip.so")
+LIB_PATH = os.environ.get("PMI_LIB") or os.path.join(_HERE, "csrc", "libperceptor_hip.so")   # PMI_LIB: diagnostic builds (tools/ only)
 
 DT_F16, DT_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU, ACT_QUICKGELU = 0, 1, 2, 3, 4
@@ -40,6 +40,7 @@ class IgemmArgs(C.Structure):
         ("sA_o", C.c_int64), ("sA_i", C.c_int64), ("sB_o", C.c_int64), ("sB_i", C.c_int64),
         ("sD_o", C.c_int64), ("sD_i", C.c_int64), ("sR_o", C.c_int64), ("sR_i", C.c_int64),
         ("dtype", C.c_int32), ("ldnb", C.c_int32), ("pro_act", C.c_int32), ("stats_p", C.c_int32), ("splitk", C.c_int32), ("reserved", C.c_int32),
+        ("Bf", C.c_void_p),
     ]
 
 

@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libperceptor_hip.so")
-SOURCES = ["igemm.hip", "conv3x3.hip", "norm.hip", "attn.hip", "elementwise.hip", "clip.hip", "gemm_lt.hip"]
+SOURCES = ["igemm.hip", "conv3x3.hip", "conv_wd.hip", "norm.hip", "attn.hip", "elementwise.hip", "clip.hip", "gemm_lt.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 
 
@@ -19,17 +19,21 @@ def _stale(out: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, variant: str = "", extra_flags=()) -> str:
+    """variant / extra_flags: diagnostic builds for tools/ (e.g. variant="stamps", extra_flags=["-DPMI_STAMPS"]) written next
+    to the product library as libperceptor_hip_<variant>.so; the product build takes neither."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    lib = LIB if not variant else LIB.replace(".so", f"_{variant}.so")
+    bdir = "build" if not variant else f"build_{variant}"
     hdrs = [os.path.join(HERE, "common.h"), os.path.join(HERE, "..", "..", "include", "perceptor_hip.h")]
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
     objs = []
 
     def compile_one(src):
-        obj = os.path.join(HERE, "build", src.replace(".hip", ".o"))
+        obj = os.path.join(HERE, bdir, src.replace(".hip", ".o"))
         os.makedirs(os.path.dirname(obj), exist_ok=True)
         if force or _stale(obj, [os.path.join(HERE, src)] + hdrs):
-            cmd = [hipcc, *FLAGS, "-c", os.path.join(HERE, src), "-o", obj]
+            cmd = [hipcc, *FLAGS, *extra_flags, "-c", os.path.join(HERE, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
@@ -37,13 +41,16 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=min(7, len(srcs))) as ex:
         objs = list(ex.map(compile_one, srcs))
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lhipblaslt"]   # hipBLASLt: plain library GEMMs only
+    if force or _stale(lib, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, "-L/opt/rocm/lib", "-lhipblaslt"]   # hipBLASLt: plain library GEMMs only
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--stamps" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, variant="stamps", extra_flags=["-DPMI_STAMPS"]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

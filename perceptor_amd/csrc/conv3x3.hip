@@ -412,6 +412,8 @@ int launch_t(const pmi_igemm_args& a, hipStream_t s, int cfg) {
 // Returns the config the halo kernel can run (0: 8x32 x 256ch, 1: 16x32 x 128ch) or -1 if the shape needs the generic kernel.
 static int g_prefer0 = 1;      // pmi_set_option(2, v): prefer the 8-wave 256-channel config where the grid allows (A/B)
 static int g_force_cfg = -1;   // pmi_set_option(1, cfg): force a tile config where eligible (A/B benchmarking)
+static int g_wd = 1;           // pmi_set_option(6, v): allow the weights-direct kernel (conv_wd.hip) where fragment-ordered weights are given
+void pmi_conv3x3_allow_wd(int v) { g_wd = v; }
 void pmi_conv3x3_force_config(int cfg) { g_force_cfg = cfg; }
 void pmi_conv3x3_use_glds(int v) { g_prefer0 = v; }      // experiments measured and dropped: direct-to-LDS weights, persistent tiles, start stagger
 void pmi_conv3x3_persistent(int) {}    // incremental patch staging: measured (876 vs 943 TFLOP/s) and dropped
@@ -425,6 +427,16 @@ extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
   // config 3: at most 32 output channels (the UNet's last conv, 128 -> 6): one MFMA block column per wave
   if (a->N <= 32 && (a->N % 4) == 0 && !a->stats && !a->res_up && a->M / (a->H * a->W) * (a->H / 8) * (a->W / 32) >= 256) return 3;
   if ((a->N % 128) || a->out_f32 || (a->R && a->res_f32)) return -1;
+  if (a->Bf && g_wd) {            // weights-direct kernel: 4 = 256-channel tiles (64-channel chunks), 5 = 128-channel tiles (32-channel chunks)
+    const int t8 = a->M / (a->H * a->W) * (a->H / 8) * (a->W / 32);
+    const bool ok4 = (a->N % 256) == 0, ok5 = true;
+    if (g_force_cfg == 4 && ok4) return 4;
+    if (g_force_cfg == 5 && ok5) return 5;
+    if (g_force_cfg < 0) {
+      if (ok4 && t8 * (a->N / 256) >= 192) return 4;
+      // config 5 (128-channel tiles) is not ahead of config 2 yet (twice the patch staging per MFMA): forced only
+    }
+  }
   const bool ok0 = (a->N % 256) == 0 || a->N >= 256, ok1 = (a->H % 16) == 0;
   if (g_force_cfg == 0 && ok0) return 0;
   if (g_force_cfg == 1 && ok1) return 1;

@@ -506,6 +506,8 @@ int launch(const pmi_igemm_args& a, hipStream_t s) {
 
 extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a);
 int pmi_conv3x3_halo_launch(const pmi_igemm_args* a, int cfg, void* stream);
+int pmi_conv3x3_wd_launch(const pmi_igemm_args* a, int cfg, void* stream);   // conv_wd.hip: tile configs 4, 5
+void pmi_conv3x3_allow_wd(int v);
 int pmi_gemm_lt(const pmi_igemm_args* a, void* stream);          // gemm_lt.hip: 0 = done by hipBLASLt, 1 = use the generic kernel
 int pmi_gemm_lt_eligible(const pmi_igemm_args* a);
 void pmi_gemm_lt_enable(int v);
@@ -545,6 +547,7 @@ extern "C" int pmi_set_option(int key, int value) {
   if (key == 3) { pmi_conv3x3_persistent(value); return 0; }
   if (key == 4) { pmi_gemm_lt_enable(value); return 0; }
   if (key == 5) { pmi_gemm_lt_margin(value); return 0; }
+  if (key == 6) { pmi_conv3x3_allow_wd(value); return 0; }
   return PMI_ERR_ARG;
 }
 
@@ -570,6 +573,7 @@ extern "C" int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream) {
   if (a->pro_a && (!a->pro_b || halo < 0)) return PMI_ERR_ARG;
   if (a->stats && a->stats_p != pmi_igemm_stats_rows(a)) return PMI_ERR_ARG;
   if (a->splitk > 1 && (!a->ws || a->batch > 1 || halo >= 0 || (a->N & 3) || a->stats)) return PMI_ERR_ARG;
+  if (halo >= 4) return pmi_conv3x3_wd_launch(a, halo, stream);
   if (halo >= 0) return pmi_conv3x3_halo_launch(a, halo, stream);
   if (pmi_gemm_lt(a, stream) == PMI_OK) return PMI_OK;           // plain GEMMs go to hipBLASLt when it has a kernel for the shape
   hipStream_t s = (hipStream_t)stream;

@@ -17,6 +17,7 @@ from .._hip import ACT_NONE, IgemmArgs, call, ptr
 
 HALO_ENABLED = True
 SPLITK_ENABLED = True
+WD_ENABLED = True       # weights-direct conv3x3 kernel (csrc/conv_wd.hip) where the shape is eligible
 
 
 def set_halo(enabled: bool) -> None:
@@ -58,10 +59,21 @@ class PackedLinear:
             b[:cout] = bias.detach().float()
             self.b = b.to(device)
         self.dt = dt
+        self._frag = {}
 
     @property
     def K(self):
         return self.taps * self.cin_p
+
+    def frag(self, ck: int) -> torch.Tensor:
+        """The 3x3 weights in MFMA fragment order for the weights-direct kernel (csrc/conv_wd.hip):
+        [N/32][Cin/ck][dx][ck/16][dy][lane = 32*(k half) + channel][8 k] -- every (n-block, chunk, dx, k-step, dy)
+        fragment is one contiguous 1 KB piece and a wave's whole weight stream is contiguous in its loop order."""
+        if ck not in self._frag:
+            assert self.taps == 9 and self.n_p % 32 == 0 and self.cin_p % ck == 0
+            w = self.w.view(self.n_p // 32, 32, 3, 3, self.cin_p // ck, ck // 16, 2, 8)   # nb, l31, dy, dx, chunk, ks, h, j
+            self._frag[ck] = w.permute(0, 4, 3, 5, 2, 6, 1, 7).contiguous()
+        return self._frag[ck]
 
 
 def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
@@ -107,6 +119,10 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
     a.ldnb = nbias.stride(0) if nbias is not None else 0
     a.batch, a.batch_inner = 1, 1
     a.dtype = dt
+    if conv and lin.taps == 9 and stride == 1 and HALO_ENABLED and WD_ENABLED and lin.n_p % 128 == 0 and lin.cin_p % 64 == 0:
+        a.Bf = 1                       # ask which tile config the weights-direct kernel would run, then hand it that packing
+        cfg = _hip.lib().pmi_conv3x3_halo_config(C.byref(a))
+        a.Bf = ptr(lin.frag(64 if cfg == 4 else 32)) if cfg in (4, 5) else None
     if prologue is not None:
         ca, cb, pact = prologue
         if HALO_ENABLED and _hip.lib().pmi_conv3x3_halo_config(C.byref(a)) >= 0:

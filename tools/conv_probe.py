@@ -47,7 +47,7 @@ if a.stamps:
     # needs conv3x3.hip built with -DPMI_STAMPS: per-workgroup wall_clock64 (100 MHz) at entry / first barrier / main loop end /
     # epilogue end / exit, plus HW_ID and XCC_ID
     ops.set_halo(True)
-    ws = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
+    ws = torch.zeros(1 << 20, dtype=torch.int64, device=dev)   # [0, 2^19): phase stamps, 8 per workgroup; [2^19, ...): 4 per wave
     ops.DEBUG_WS = ws
     ops.igemm(x, lin, prologue=pro, out=out, residual=res, want_stats=bool(a.stats))
     torch.cuda.synchronize()
@@ -61,6 +61,17 @@ if a.stamps:
     for nm, k0, k1 in (("prologue", 0, 1), ("mainloop", 1, 2), ("epilogue", 2, 3), ("stats+exit", 3, 4), ("total", 0, 4)):
         d = t[:, k1] - t[:, k0]
         print(f"  {nm:10s} mean {us(d.mean()):8.2f} us  min {us(d.min()):8.2f}  max {us(d.max()):8.2f}")
+    if (st[:, 6] > 0).any():
+        t6, t7 = st[:, 6].double(), st[:, 7].double()
+        print(f"  epilogue split: acc->LDS {us((t6 - t[:, 2]).mean()):.2f} us, write-out {us((t7 - t6).mean()):.2f} us, stats/drain {us((t[:, 3] - t7).mean()):.2f} us")
+    cw = ws.cpu()[(1 << 19):(1 << 19) + len(st) * 32].view(-1, 4).double()     # per wave: s_memtime at loop start / end, wall clock at both
+    cw = cw[cw[:, 0] > 0]
+    if len(cw):
+        dcyc, dwall = cw[:, 1] - cw[:, 0], (cw[:, 3] - cw[:, 2]) * 0.01
+        print(f"  per-wave main loop: mean {float(dwall.mean()):.2f} us  min {float(dwall.min()):.2f}  max {float(dwall.max()):.2f};  shader clock in the loop {float((dcyc / dwall).median()) / 1e3:.3f} GHz")
+        w8 = dwall.view(-1, 8) if len(dwall) % 8 == 0 else None
+        if w8 is not None:
+            print("  main loop by wave id (us): " + " ".join(f"{float(v):.1f}" for v in w8.mean(0)))
     hw = st[:, 5]
     cu = ((hw >> 32) & 0xf) * 1024 + ((hw >> 13) & 0x7) * 64 + ((hw >> 8) & 0xf) * 4 + ((hw >> 12) & 1)   # xcc, se, cu, sh (ids only used to group)
     ids = cu.unique()
