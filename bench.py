@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """bench.py — denoising steps/s of the guided-diffusion sampling hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+N > 1 without a torch.distributed.run environment: this process parses the arguments and, before it touches the GPU,
+starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child (one rank per GPU over RCCL), relays
+rank 0's JSON line and exits with the child's code.  Under torch.distributed.run (WORLD_SIZE set) it is a rank.
 
 Workload (BASELINE.json metric "denoising steps/sec (UNet+CLIP-grad) at 512x512 batch 8"):
   config c5 (default) = configs[4] per-GPU share: GuidedDiffusion "standard" UNet @512x512,
@@ -55,7 +58,53 @@ def parse():
     p.add_argument("--lt-margin", type=int, default=None, help="percent a hipBLASLt candidate must beat the heuristic pick by to replace it (A/B)")
     p.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (helps launch-bound small configs such as c1)")
     p.add_argument("--dump-kernels", default=None, help="write per-launch (ms, GFLOP, MB) of the timed conv3x3 launches of the last step to this file")
+    p.add_argument("--rehearse", action="store_true", help="launcher / collective rehearsal without the model: every rank joins the process group "
+                                                            "(gloo when there is no GPU), all-gathers a small tensor and rank 0 prints a JSON line")
     return p.parse_args()
+
+
+def self_launch(a) -> int:
+    """--gpus N > 1 outside torch.distributed.run: start the N ranks as fresh child processes (this parent has made no GPU call),
+    stream their output through, return the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL across processes on this host driver)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rehearse(a, rank, local_rank, world):
+    """Process-group plumbing only: init, all_gather, barrier, max-reduced time, JSON line on rank 0."""
+    import torch.distributed as dist
+    use_gpu = torch.cuda.is_available() and torch.cuda.device_count() > local_rank
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    if use_gpu:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dev = torch.device("cpu")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    t0 = time.perf_counter()
+    mine = torch.full((4, 3, 8, 8), float(rank), device=dev)
+    got = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    dist.barrier()
+    ok = all(float(g.mean()) == float(r) for r, g in enumerate(got))
+    tmax = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"rehearsal": True, "n_gpus": world, "backend": "nccl" if use_gpu else "gloo", "rccl_ranks": world if use_gpu else 0,
+                          "all_gather_ok": ok, "seconds": round(float(tmax.item()), 4)}), flush=True)
+    dist.destroy_process_group()
+    return 0 if ok else 1
 
 
 def cpu_baseline_v(model_name, res):
@@ -74,24 +123,52 @@ def cpu_baseline_v(model_name, res):
     return time.time() - t0, sres, torch.get_num_threads()
 
 
-def cpu_baseline(model_name, res, clip_arch, seed=0):
-    """Oracle (CPU fp32 port of the reference path) timed on a bounded sample: batch 1 at 128x128 for the
-    UNet (+ batch-1 CLIP fwd+bwd), scaled by the FLOP ratio to the benchmark's batch/resolution."""
-    from oracle import adm_unet
+def cpu_baseline(model_name, res, nb, clip_arch, clip_loss, hip_model, dev, seed=0):
+    """Checker leg (rank 0, N = 1, outside the timed region): ONE full denoising step of the oracle -- the CPU fp32 restatement of the
+    reference path -- timed on the host cores at batch 1 and min(res, 256)^2: UNet -> denoised -> resize -> ViT forward + backward to the
+    image -> guided -> DDIM step.  The UNet and the per-pixel updates scale with batch x pixels, the CLIP leg (always 224^2) with batch.
+    The same sample is run through the HIP model: max |eps_hip - eps_oracle| is the parity figure of the timed mode."""
+    from oracle import adm_unet, clip_vit, sampling
     from perceptor_amd.utils.synth import seeded_noise, synth_state_dict
     cores = torch.get_num_threads()
     cfg = adm_unet.openimages_config() if model_name == "standard" else adm_unet.pixelart_config()
     sd = synth_state_dict(adm_unet.state_dict_shapes(cfg), seed)
-    sres = 128 if res >= 128 else res
+    sres = min(res, 256)
     x = seeded_noise((1, 3, sres, sres), 1234)
-    t = torch.tensor([500])
-    adm_unet.adm_unet_forward(sd, cfg, x, t)              # warm-up
-    t0 = time.time()
-    reps = 2
-    for _ in range(reps):
-        adm_unet.adm_unet_forward(sd, cfg, x, t)
-    t_unet = (time.time() - t0) / reps
-    return t_unet, sres, cores
+    images = x * 0.5 + 0.5
+    fi, ti = torch.tensor([600]), torch.tensor([550])
+    al, sg = sampling.gd_tables()
+    vcfg = clip_vit.VIT_CONFIGS[clip_arch] if clip_arch else None
+    vsd = synth_state_dict(clip_vit.vit_state_dict_shapes(vcfg), 0) if clip_arch else None
+    targets = clip_loss.encodings.detach().cpu().float() if clip_arch else None
+
+    def step():
+        t0 = time.time()
+        eps = adm_unet.adm_unet_forward(sd, cfg, x, fi)[:, :3]
+        t1 = time.time()
+        den = (sampling.eps_denoised_xs(images, eps, al[fi], sg[fi]) + 1) / 2
+        if clip_arch:
+            _, grad = clip_vit.clip_loss_and_grad(vsd, vcfg, den, targets, torch.ones(len(targets)), clip_loss.model.quick_gelu)
+            eps_g = sampling.guided(eps, grad, sg[fi], 0.5, 1e-6)
+        else:
+            eps_g = eps
+        t2 = time.time()
+        nxt = sampling.eps_step(images, eps_g, al[fi], sg[fi], al[ti], sg[ti])
+        t3 = time.time()
+        return eps, nxt, (t1 - t0, t2 - t1, t3 - t2)
+
+    step()                                                     # warm-up (allocator, thread pool)
+    eps_ref, _, (t_unet, t_clip, t_upd) = step()
+    scale_px = (res / sres) ** 2 * nb
+    sec_step = t_unet * scale_px + t_clip * nb + t_upd * scale_px
+    parity = None
+    if hip_model is not None:
+        eps_hip = hip_model.predicted_noise(images.to(dev), fi.to(dev)).float().cpu()
+        parity = {"eps_max_abs_err": float((eps_hip - eps_ref).abs().max()), "eps_max_abs": float(eps_ref.abs().max()),
+                  "sample": f"batch 1 @{sres}x{sres}, index 600, vs the CPU fp32 oracle on the same weights and input"}
+    sample = (f"one full oracle step at batch 1 @{sres}x{sres}: UNet {t_unet:.2f}s + CLIP {clip_arch or 'none'} fwd+bwd and guidance {t_clip:.2f}s + update {t_upd:.3f}s; "
+              f"UNet/update scaled x{scale_px:.0f} (batch x pixels), CLIP leg x{nb} (batch)")
+    return sec_step, sample, cores, parity
 
 
 def main():
@@ -99,9 +176,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(self_launch(a))                 # parent: no GPU call made, children are fresh processes
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {a.gpus}")
+    if a.rehearse:
+        raise SystemExit(rehearse(a, rank, local_rank, world))
     torch.cuda.set_device(local_rank)            # before the process group: RCCL binds its communicator to the current device
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -235,15 +315,23 @@ def main():
                                    + ", DDIM eta=0, synthetic weights", "name": a.config,
                        "global_batch": nb * world, "parallelism": f"replica-sharded chains x{world}"},
             "outputs_finite": finite,
+            "rccl_ranks": world if dist is not None else 0,
             "roofline": roof,
         }
         if not a.no_cpu_baseline and world == 1:
-            t_unet, sres, cores = cpu_baseline_v(model_name, res) if is_v else cpu_baseline(model_name, res, clip_arch)
-            scale = (res / sres) ** 2 * nb
-            sec_step = t_unet * scale * (gflop_sample / UNET_GFLOP[model_name][res])
+            if is_v:
+                t_unet, sres, cores = cpu_baseline_v(model_name, res)
+                scale = (res / sres) ** 2 * nb
+                sec_step = t_unet * scale * (gflop_sample / UNET_GFLOP[model_name][res])
+                sample = (f"oracle UNet fwd batch 1 @{sres}x{sres} = {t_unet:.2f}s, scaled x{scale:.0f} by pixel*batch"
+                          f" and x{gflop_sample / UNET_GFLOP[model_name][res]:.3f} for the CLIP FLOP share")
+                parity = None
+            else:
+                sec_step, sample, cores, parity = cpu_baseline(model_name, res, nb, clip_arch, clip_loss, model, dev)
             out["cpu_baseline"] = {"value": round(1.0 / sec_step, 6), "unit": f"steps/s (batch-{nb} steps)", "cores": cores, "kind": "port",
-                                   "sample": f"oracle UNet fwd batch 1 @{sres}x{sres} = {t_unet:.2f}s, scaled x{scale:.0f} by pixel*batch"
-                                             f" and x{gflop_sample / UNET_GFLOP[model_name][res]:.3f} for the CLIP FLOP share"}
+                                   "sample": sample}
+            if parity is not None:
+                out["parity"] = parity
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -60,7 +60,7 @@ typedef struct {
   float alpha;
   int32_t batch, batch_inner; /* grid.z batches: z -> (z / batch_inner, z % batch_inner) */
   int64_t sA_o, sA_i, sB_o, sB_i, sD_o, sD_i, sR_o, sR_i; /* element strides */
-  int32_t dtype;       /* 0 f16, 1 bf16 */
+  int32_t dtype;       /* 0 f16, 1 bf16, 2 precise (f16 MFMA on hi + lo pairs, see split_out) */
   int32_t ldnb;        /* row pitch of nbias (0 = N) */
   int32_t pro_act;     /* activation of the fused prologue */
   int32_t stats_p;     /* partial rows per image = pmi_igemm_stats_rows(); 0 = no statistics */
@@ -68,6 +68,10 @@ typedef struct {
   int32_t reserved;
   const void* Bf;      /* optional: the same weights in MFMA fragment order for the weights-direct conv3x3 kernel (csrc/conv_wd.hip),
                         * [N/32][Cin/ck][3 dx][ck/16][3 dy][64 lanes][8] 16-bit with ck = 64 (tile config 4) or 32 (config 5); NULL = not packed */
+  int32_t split_out;   /* "precise" mode (dtype 2): D (and a 16-bit R) hold hi + lo f16 pairs in groups of split_out (8 or 32) logical channels,
+                        * ldd / ldr count 16-bit elements of the 2N-wide rows; 0 = plain.  A split INPUT needs no flag: it is a tensor with 2 Cin
+                        * channels whose weights are duplicated along K by the caller.  Generic kernel only (no LDS-halo config). */
+  int32_t split_in;    /* 1: the inputs are precise (hi + lo) tensors -> generic kernel only (a fused prologue would act on the two parts separately) */
 } pmi_igemm_args;
 int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream);
 /* >= 0 when an LDS-halo conv3x3 kernel takes this shape.  csrc/conv3x3.hip: tile config 0: 8x32 px x 256 ch, 1: 16x32 x 128, 2: 8x32 x 128 with two
@@ -84,6 +88,23 @@ int pmi_igemm_stats_rows(const pmi_igemm_args* a);
  * key 4 = route plain GEMMs (one source, no convolution gather, no fused activation / statistics) to hipBLASLt (default 1);
  * key 5 = percent by which a hipBLASLt candidate must beat the heuristic's first pick to replace it when a shape is first timed (default 8). */
 int pmi_set_option(int key, int value);
+
+/* ---- "precise" mode helpers (dtype 2: hi + lo f16 pairs, eps max-abs error < 1e-3 vs the fp32 reference path) ----------------
+ * exact-fp32 batched GEMM on the f32-input MFMA: D[b][m][n] = act(alpha * sum_k A[b][m][k] * B[b][n][k] + bias[n]); transB: B is [k][n].
+ * Replaces the attention einsums of unet.py:332-348 / yfcc_2.py:62-70 and the time MLPs (unet.py:462-467) in that mode. */
+typedef struct {
+  const float* A; const float* B; const float* bias; float* D;
+  int32_t M, N, K, lda, ldb, ldd;
+  int32_t transB, act;
+  float alpha;
+  int32_t batch, batch_inner;          /* grid.z batches: z -> (z / batch_inner, z % batch_inner) */
+  int64_t sA_o, sA_i, sB_o, sB_i, sD_o, sD_i;
+} pmi_gemm_f32_args;
+int pmi_gemm_f32(const pmi_gemm_f32_args* a, pmi_stream_t stream);
+int pmi_softmax_f32(float* S, int rows, int T, int ld, float scale, pmi_stream_t s);   /* in place, fp32 (unet.py:346) */
+/* fp32 [rows][C] (row pitch ld_in) <-> precise [rows][2C] */
+int pmi_split_from_f32(const float* in, int ld_in, void* out, int64_t rows, int C, pmi_stream_t s);
+int pmi_split_to_f32(const void* in, float* out, int64_t rows, int C, pmi_stream_t s);
 
 /* ---- GroupNorm (+FiLM, +activation, +2x2 average pool) ---------------------------
  * unet.py:232-252 / nn.py:17-19 (GroupNorm32 -> SiLU, FiLM h*(1+scale)+shift),

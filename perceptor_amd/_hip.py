@@ -14,9 +14,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PMI_LIB") or os.path.join(_HERE, "csrc", "libperceptor_hip.so")   # PMI_LIB: diagnostic builds (tools/ only)
 
-DT_F16, DT_BF16 = 0, 1
+DT_F16, DT_BF16, DT_F16X2 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU, ACT_QUICKGELU = 0, 1, 2, 3, 4
-TORCH_DTYPE = {DT_F16: torch.float16, DT_BF16: torch.bfloat16}
+TORCH_DTYPE = {DT_F16: torch.float16, DT_BF16: torch.bfloat16, DT_F16X2: torch.float16}
 
 
 def dtype_code(name) -> int:
@@ -24,7 +24,9 @@ def dtype_code(name) -> int:
         return DT_F16
     if name in (DT_BF16, "bf16", torch.bfloat16):
         return DT_BF16
-    raise ValueError(f"unsupported compute dtype {name!r} (f16 or bf16)")
+    if name in (DT_F16X2, "precise", "f16x2"):
+        return DT_F16X2
+    raise ValueError(f"unsupported compute dtype {name!r} (f16, bf16 or precise)")
 
 
 class IgemmArgs(C.Structure):
@@ -40,8 +42,15 @@ class IgemmArgs(C.Structure):
         ("sA_o", C.c_int64), ("sA_i", C.c_int64), ("sB_o", C.c_int64), ("sB_i", C.c_int64),
         ("sD_o", C.c_int64), ("sD_i", C.c_int64), ("sR_o", C.c_int64), ("sR_i", C.c_int64),
         ("dtype", C.c_int32), ("ldnb", C.c_int32), ("pro_act", C.c_int32), ("stats_p", C.c_int32), ("splitk", C.c_int32), ("reserved", C.c_int32),
-        ("Bf", C.c_void_p),
+        ("Bf", C.c_void_p), ("split_out", C.c_int32), ("split_in", C.c_int32),
     ]
+
+
+class GemmF32Args(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("bias", C.c_void_p), ("D", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldd", C.c_int32),
+                ("transB", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float), ("batch", C.c_int32), ("batch_inner", C.c_int32),
+                ("sA_o", C.c_int64), ("sA_i", C.c_int64), ("sB_o", C.c_int64), ("sB_i", C.c_int64), ("sD_o", C.c_int64), ("sD_i", C.c_int64)]
 
 
 _lib = None
@@ -54,6 +63,10 @@ _PROTOS = {
     "pmi_igemm_stats_rows": ([C.POINTER(IgemmArgs)],),
     "pmi_igemm_splitk": ([C.POINTER(IgemmArgs)],),
     "pmi_set_option": ([_I, _I],),
+    "pmi_gemm_f32": ([C.POINTER(GemmF32Args), _P],),
+    "pmi_softmax_f32": ([_P, _I, _I, _I, _F, _P],),
+    "pmi_split_from_f32": ([_P, _I, _P, _L, _I, _P],),
+    "pmi_split_to_f32": ([_P, _P, _L, _I, _P],),
     "pmi_gn_stats": ([_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],),
     "pmi_gn_finalize": ([_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _F, _P],),
     "pmi_gn_apply": ([_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],),

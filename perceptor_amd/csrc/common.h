@@ -9,6 +9,7 @@
 
 #define PMI_DT_F16 0
 #define PMI_DT_BF16 1
+#define PMI_DT_F16X2 2   /* "precise": every activation value is a hi + lo pair of f16 (~22 significant bits), see F16X2 below */
 
 #define PMI_ACT_NONE 0
 #define PMI_ACT_RELU 1
@@ -70,6 +71,52 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
   for (int i = 0; i < 4; ++i) w[i] = (uint32_t)T::from_f(f[2 * i]) | ((uint32_t)T::from_f(f[2 * i + 1]) << 16);
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
+// ---- "precise" activations (PMI_DT_F16X2) --------------------------------------------------------------------------
+// A logical tensor with C channels is stored as 2C f16 per pixel: per group of G = min(32, C) channels first the G high
+// parts hi = f16(x), then the G low parts lo = f16(x - hi).  hi + lo carries ~22 bits.  A convolution over such a tensor with
+// the weights duplicated along K ([W | W] per group) is W*hi + W*lo with fp32 accumulation on the f16 MFMA, i.e. an fp32-grade
+// product for f16-representable weights -- the MFMA main loops are unchanged, only loads of single values (GroupNorm, pooling,
+// epilogues) add the two parts and stores split them again.
+struct F16X2 : F16 {};
+template <typename T> struct is_split { static constexpr bool v = false; };
+template <> struct is_split<F16X2> { static constexpr bool v = true; };
+template <typename T> __device__ __forceinline__ int row_elems(int C) { return is_split<T>::v ? 2 * C : C; }
+__device__ __forceinline__ int split_group(int C) { return C < 32 ? C : 32; }
+__device__ __forceinline__ int split_off(int c, int G) { return (c / G) * 2 * G + (c % G); }     // offset of the high part; low part at + G
+
+// 8 consecutive logical channels starting at c (multiple of 8) of the pixel whose channels start at `row`
+template <typename T>
+__device__ __forceinline__ void load8(const u16* row, int c, int C, float* f) {
+  if constexpr (is_split<T>::v) {
+    const int G = split_group(C), o = split_off(c, G);
+    float lo[8];
+    unpack8<F16>(*(const uint4*)(row + o), f);
+    unpack8<F16>(*(const uint4*)(row + o + G), lo);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] += lo[e];
+  } else {
+    unpack8<T>(*(const uint4*)(row + c), f);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store8(u16* row, int c, int C, const float* f) {
+  if constexpr (is_split<T>::v) {
+    const int G = split_group(C), o = split_off(c, G);
+    float lo[8];
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u16 h0 = F16::from_f(f[2 * i]), h1 = F16::from_f(f[2 * i + 1]);
+      lo[2 * i] = f[2 * i] - F16::to_f(h0); lo[2 * i + 1] = f[2 * i + 1] - F16::to_f(h1);
+      w[i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+    }
+    *(uint4*)(row + o) = make_uint4(w[0], w[1], w[2], w[3]);
+    *(uint4*)(row + o + G) = pack8<F16>(lo);
+  } else {
+    *(uint4*)(row + c) = pack8<T>(f);
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
   return make_uint2((uint32_t)T::from_f(a) | ((uint32_t)T::from_f(b) << 16),

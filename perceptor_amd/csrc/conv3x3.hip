@@ -421,7 +421,7 @@ void pmi_conv3x3_persistent(int) {}    // incremental patch staging: measured (8
 // Returns the tile config the halo kernel runs for this shape (0: 8x32 px x 256 ch / 8 waves, 1: 16x32 x 128 / 8 waves,
 // 2: 8x32 x 128 / 4 waves x 2 workgroups per CU, 3: 8x32 px x <= 32 channels) or -1 if the shape needs the generic kernel.
 extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
-  if (a->taps != 9 || a->stride != 1 || a->batch > 1) return -1;
+  if (a->taps != 9 || a->stride != 1 || a->batch > 1 || a->split_out || a->split_in) return -1;
   const int Cin = a->C0 + a->C1;
   if ((Cin % 64) || (a->C0 % 64) || (a->W % 32) || (a->H % 8)) return -1;
   // config 3: at most 32 output channels (the UNet's last conv, 128 -> 6): one MFMA block column per wave

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void prep_input_kernel(const float* __restrict
       else if (c < 3 + nplanes) v = planes[(int64_t)n * nplanes + (c - 3)];
       f[e] = v;
     }
-    *(uint4*)(x + pix * Cpad + c8 * 8) = pack8<T>(f);
+    store8<T>(x + pix * row_elems<T>(Cpad), c8 * 8, Cpad, f);
   }
 }
 
@@ -55,13 +55,14 @@ __global__ __launch_bounds__(256) void avgpool2_kernel(const u16* __restrict__ x
     const int n = (int)(pix / ((int64_t)Ho * Wo));
     const int rem = (int)(pix - (int64_t)n * Ho * Wo);
     const int oy = rem / Wo, ox = rem - oy * Wo;
-    const u16* b = x + (((int64_t)n * H + 2 * oy) * W + 2 * ox) * C + c8 * 8;
+    const int ld = row_elems<T>(C);
+    const u16* b = x + (((int64_t)n * H + 2 * oy) * W + 2 * ox) * ld;
     float a0[8], a1[8], a2[8], a3[8], o[8];
-    unpack8<T>(*(const uint4*)b, a0); unpack8<T>(*(const uint4*)(b + C), a1);
-    unpack8<T>(*(const uint4*)(b + (int64_t)W * C), a2); unpack8<T>(*(const uint4*)(b + (int64_t)W * C + C), a3);
+    load8<T>(b, c8 * 8, C, a0); load8<T>(b + ld, c8 * 8, C, a1);
+    load8<T>(b + (int64_t)W * ld, c8 * 8, C, a2); load8<T>(b + (int64_t)W * ld + ld, c8 * 8, C, a3);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.25f * (a0[e] + a1[e] + a2[e] + a3[e]);
-    *(uint4*)(y + pix * C + c8 * 8) = pack8<T>(o);
+    store8<T>(y + pix * ld, c8 * 8, C, o);
   }
 }
 
@@ -79,15 +80,16 @@ __global__ __launch_bounds__(256) void upsample_bilinear2_kernel(const u16* __re
     const int iy = oy >> 1, ix = ox >> 1;
     const int y1 = (oy & 1) ? min(iy + 1, H - 1) : max(iy - 1, 0);
     const int x1 = (ox & 1) ? min(ix + 1, W - 1) : max(ix - 1, 0);
-    const u16* b = x + (int64_t)n * H * W * C + c8 * 8;
+    const int ld = row_elems<T>(C);
+    const u16* b = x + (int64_t)n * H * W * ld;
     float a00[8], a01[8], a10[8], a11[8], o[8];
-    unpack8<T>(*(const uint4*)(b + ((int64_t)iy * W + ix) * C), a00);
-    unpack8<T>(*(const uint4*)(b + ((int64_t)iy * W + x1) * C), a01);
-    unpack8<T>(*(const uint4*)(b + ((int64_t)y1 * W + ix) * C), a10);
-    unpack8<T>(*(const uint4*)(b + ((int64_t)y1 * W + x1) * C), a11);
+    load8<T>(b + ((int64_t)iy * W + ix) * ld, c8 * 8, C, a00);
+    load8<T>(b + ((int64_t)iy * W + x1) * ld, c8 * 8, C, a01);
+    load8<T>(b + ((int64_t)y1 * W + ix) * ld, c8 * 8, C, a10);
+    load8<T>(b + ((int64_t)y1 * W + x1) * ld, c8 * 8, C, a11);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.75f * (0.75f * a00[e] + 0.25f * a01[e]) + 0.25f * (0.75f * a10[e] + 0.25f * a11[e]);
-    *(uint4*)(y + pix * C + c8 * 8) = pack8<T>(o);
+    store8<T>(y + pix * ld, c8 * 8, C, o);
   }
 }
 
@@ -113,8 +115,37 @@ __global__ void timestep_embedding_kernel(const float* __restrict__ t, u16* __re
   const int n = i / half, j = i - n * half;
   const float freq = expf(-logf(max_period) * (float)j / (float)half);
   const float arg = t[n] * freq;
-  out[(int64_t)n * dim + j] = T::from_f(cosf(arg));
-  out[(int64_t)n * dim + half + j] = T::from_f(sinf(arg));
+  if constexpr (is_split<T>::v) {            // precise mode: fp32 features for the fp32 time MLP
+    ((float*)out)[(int64_t)n * dim + j] = cosf(arg);
+    ((float*)out)[(int64_t)n * dim + half + j] = sinf(arg);
+  } else {
+    out[(int64_t)n * dim + j] = T::from_f(cosf(arg));
+    out[(int64_t)n * dim + half + j] = T::from_f(sinf(arg));
+  }
+}
+
+// fp32 [rows][C] <-> precise (hi + lo f16 pairs) [rows][2C]
+__global__ __launch_bounds__(256) void split_from_f32_kernel(const float* __restrict__ in, int ld_in, u16* __restrict__ out, int64_t rows, int C) {
+  const int C8 = C >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * C8; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t r = i / C8;
+    float f[8];
+    *(float4*)f = *(const float4*)(in + r * ld_in + c8 * 8);
+    *(float4*)(f + 4) = *(const float4*)(in + r * ld_in + c8 * 8 + 4);
+    store8<F16X2>(out + r * 2 * C, c8 * 8, C, f);
+  }
+}
+__global__ __launch_bounds__(256) void split_to_f32_kernel(const u16* __restrict__ in, float* __restrict__ out, int64_t rows, int C) {
+  const int C8 = C >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * C8; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t r = i / C8;
+    float f[8];
+    load8<F16X2>(in + r * 2 * C, c8 * 8, C, f);
+    *(float4*)(out + r * C + c8 * 8) = *(const float4*)f;
+    *(float4*)(out + r * C + c8 * 8 + 4) = *(const float4*)(f + 4);
+  }
 }
 
 __global__ void fourier_features_kernel(const float* __restrict__ t, const float* __restrict__ w, float* __restrict__ out, int N, int half) {
@@ -202,6 +233,7 @@ __global__ __launch_bounds__(256) void clamp_kernel(const float* __restrict__ a,
 #define BY_DTYPE(KERN, ...)                                                              \
   do {                                                                                   \
     if (dtype == PMI_DT_BF16) hipLaunchKernelGGL(KERN<BF16>, grid, block, 0, ST, __VA_ARGS__); \
+    else if (dtype == PMI_DT_F16X2) hipLaunchKernelGGL(KERN<F16X2>, grid, block, 0, ST, __VA_ARGS__); \
     else hipLaunchKernelGGL(KERN<F16>, grid, block, 0, ST, __VA_ARGS__);                 \
   } while (0)
 
@@ -242,6 +274,18 @@ extern "C" int pmi_timestep_embedding(const float* t, void* out, int N, int dim,
   if (!t || !out || N <= 0 || dim <= 0 || (dim & 1)) return PMI_ERR_ARG;
   dim3 grid((N * dim / 2 + 255) / 256), block(256);
   BY_DTYPE(timestep_embedding_kernel, t, (u16*)out, N, dim, max_period);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_split_from_f32(const float* in, int ld_in, void* out, int64_t rows, int C, pmi_stream_t s) {
+  if (!in || !out || rows <= 0 || C <= 0 || (C & 7) || (C > 32 && (C & 31)) || (ld_in & 3)) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(split_from_f32_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, ST, in, ld_in, (u16*)out, rows, C);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_split_to_f32(const void* in, float* out, int64_t rows, int C, pmi_stream_t s) {
+  if (!in || !out || rows <= 0 || C <= 0 || (C & 7) || (C > 32 && (C & 31))) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(split_to_f32_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, ST, (const u16*)in, out, rows, C);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }

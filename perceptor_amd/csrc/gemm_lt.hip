@@ -33,7 +33,7 @@ int g_enabled = 1, g_tune = 1;
 float g_margin = 0.92f;
 
 bool eligible(const pmi_igemm_args& a) {
-  if (!g_enabled) return false;
+  if (!g_enabled || a.split_out) return false;
   if (a.taps != 1 || a.up || a.stride != 1 || a.batch > 1 || a.C1 != 0 || a.A1) return false;
   if (a.nbias || a.stats || a.pro_a || a.act != PMI_ACT_NONE || a.splitk > 1 || a.res_up) return false;
   if (a.R && (a.res_f32 != 0) != (a.out_f32 != 0)) return false;

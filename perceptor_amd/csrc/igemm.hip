@@ -12,6 +12,8 @@
 // so both the ds_write_b128 staging and the ds_read_b128 fragment reads are conflict-free.
 // Global->LDS goes through registers (gathered addresses + zero fill for the conv halo);
 // the loads of k-tile t+1 are issued before the MFMAs of tile t and written after them.
+#include <cstdio>
+#include <cstdlib>
 #include "common.h"
 #include "epilogue.h"
 #include "../../include/perceptor_hip.h"
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
   // 16 bytes per lane, 8 rows x 128 B per instruction, reading a 16-bit residual the same way.  In the accumulator layout a
   // store instruction covers 32 rows x 16 bytes, which the address coalescer handles several times slower -- decisive for the
   // short-K, store-heavy 1x1 convolutions (M = 2M rows, K = 256..768).
-  const bool fast = !a.out_f32 && !a.res_up && (a.ldd & 7) == 0 && (offD & 7) == 0 && (a.N & 7) == 0 && (((uintptr_t)a.D) & 15) == 0 &&
+  const bool fast = !a.split_out && !a.out_f32 && !a.res_up && (a.ldd & 7) == 0 && (offD & 7) == 0 && (a.N & 7) == 0 && (((uintptr_t)a.D) & 15) == 0 &&
                     (!a.R || (!a.res_f32 && (a.ldr & 7) == 0 && (offR & 7) == 0 && (((uintptr_t)a.R) & 15) == 0));
   if (fast) {
     constexpr int SROW = 144;                  // staged row: 128 B + 16 B pad
@@ -378,6 +380,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
           if (mrow[i] >= a.M || n >= a.N) continue;
           if (a.res_f32) {
             rv[i][g] = *(const float4*)((const float*)a.R + offR + rrow[i] + n);
+          } else if (a.split_out) {          // hi words in .x/.y, lo words in .z/.w
+            const int po = split_off(n, a.split_out);
+            const uint2 rh = *(const uint2*)((const u16*)a.R + offR + rrow[i] + po);
+            const uint2 rl = *(const uint2*)((const u16*)a.R + offR + rrow[i] + po + a.split_out);
+            rv[i][g].x = __builtin_bit_cast(float, rh.x); rv[i][g].y = __builtin_bit_cast(float, rh.y);
+            rv[i][g].z = __builtin_bit_cast(float, rl.x); rv[i][g].w = __builtin_bit_cast(float, rl.y);
           } else {
             const uint2 r = *(const uint2*)((const u16*)a.R + offR + rrow[i] + n);
             rv[i][g].x = __builtin_bit_cast(float, r.x); rv[i][g].y = __builtin_bit_cast(float, r.y);
@@ -407,11 +415,25 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
             const uint32_t r0 = __builtin_bit_cast(uint32_t, rv[i][g].x), r1 = __builtin_bit_cast(uint32_t, rv[i][g].y);
             v[0] += T::to_f((u16)(r0 & 0xffff)); v[1] += T::to_f((u16)(r0 >> 16));
             v[2] += T::to_f((u16)(r1 & 0xffff)); v[3] += T::to_f((u16)(r1 >> 16));
+            if (a.split_out) {
+              const uint32_t l0 = __builtin_bit_cast(uint32_t, rv[i][g].z), l1 = __builtin_bit_cast(uint32_t, rv[i][g].w);
+              v[0] += T::to_f((u16)(l0 & 0xffff)); v[1] += T::to_f((u16)(l0 >> 16));
+              v[2] += T::to_f((u16)(l1 & 0xffff)); v[3] += T::to_f((u16)(l1 >> 16));
+            }
           }
         }
+        if (a.split_out) {
+          const int64_t o = offD + (int64_t)m * a.ldd + split_off(n, a.split_out);
+          const uint2 hi = pack4<T>(v[0], v[1], v[2], v[3]);
+          const float l0 = v[0] - T::to_f((u16)(hi.x & 0xffff)), l1 = v[1] - T::to_f((u16)(hi.x >> 16));
+          const float l2 = v[2] - T::to_f((u16)(hi.y & 0xffff)), l3 = v[3] - T::to_f((u16)(hi.y >> 16));
+          *(uint2*)((u16*)a.D + o) = hi;
+          *(uint2*)((u16*)a.D + o + a.split_out) = pack4<T>(l0, l1, l2, l3);
+        } else {
         const int64_t o = offD + (int64_t)m * a.ldd + n;
         if (a.out_f32) *(float4*)((float*)a.D + o) = make_float4(v[0], v[1], v[2], v[3]);
         else *(uint2*)((u16*)a.D + o) = pack4<T>(v[0], v[1], v[2], v[3]);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) { ssum[4 * g + e] += v[e]; ssq[4 * g + e] += v[e] * v[e]; }
       }
@@ -467,10 +489,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const pmi_igemm_args
         const float4 r = *(const float4*)((const float*)a.R + rrow + n);
         v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
       } else {
-        const uint2 r = *(const uint2*)((const u16*)a.R + rrow + n);
+        const int po = a.split_out ? split_off(n, a.split_out) : n;
+        const uint2 r = *(const uint2*)((const u16*)a.R + rrow + po);
         v[0] += T::to_f((u16)(r.x & 0xffff)); v[1] += T::to_f((u16)(r.x >> 16));
         v[2] += T::to_f((u16)(r.y & 0xffff)); v[3] += T::to_f((u16)(r.y >> 16));
+        if (a.split_out) {
+          const uint2 l = *(const uint2*)((const u16*)a.R + rrow + po + a.split_out);
+          v[0] += T::to_f((u16)(l.x & 0xffff)); v[1] += T::to_f((u16)(l.x >> 16));
+          v[2] += T::to_f((u16)(l.y & 0xffff)); v[3] += T::to_f((u16)(l.y >> 16));
+        }
       }
+    }
+    if (a.split_out) {
+      const int64_t o = (int64_t)m * a.ldd + split_off(n, a.split_out);
+      const uint2 hi = pack4<T>(v[0], v[1], v[2], v[3]);
+      const float l0 = v[0] - T::to_f((u16)(hi.x & 0xffff)), l1 = v[1] - T::to_f((u16)(hi.x >> 16));
+      const float l2 = v[2] - T::to_f((u16)(hi.y & 0xffff)), l3 = v[3] - T::to_f((u16)(hi.y >> 16));
+      *(uint2*)((u16*)a.D + o) = hi;
+      *(uint2*)((u16*)a.D + o + a.split_out) = pack4<T>(l0, l1, l2, l3);
+      continue;
     }
     const int64_t o = (int64_t)m * a.ldd + n;
     if (a.out_f32) *(float4*)((float*)a.D + o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -551,24 +588,32 @@ extern "C" int pmi_set_option(int key, int value) {
   return PMI_ERR_ARG;
 }
 
+// PMI_DEBUG=1 in the environment: name the argument check that rejected a call
+static int bad_arg(int line) {
+  if (getenv("PMI_DEBUG")) fprintf(stderr, "pmi_igemm: argument check at igemm.hip:%d failed\n", line);
+  return PMI_ERR_ARG;
+}
+
 extern "C" int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream) {
-  if (!a || !a->A0 || !a->B || !a->D) return PMI_ERR_ARG;
-  if (a->M <= 0 || a->N <= 0 || a->K <= 0) return PMI_ERR_ARG;
-  if ((a->K & 7) || (a->C0 & 7) || (a->C1 & 7)) return PMI_ERR_ARG;
+  if (!a || !a->A0 || !a->B || !a->D) return bad_arg(__LINE__);
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0) return bad_arg(__LINE__);
+  if ((a->K & 7) || (a->C0 & 7) || (a->C1 & 7)) return bad_arg(__LINE__);
   // a ragged N (attention scores) is allowed when the 4-wide epilogue vectors stay inside the row pitch
-  if ((a->N & 3) && (a->bias || a->nbias || a->R || a->ldd < ((a->N + 3) & ~3))) return PMI_ERR_ARG;
-  if ((a->lda0 & 7) || (a->ldb & 7) || (a->ldd & 3)) return PMI_ERR_ARG;
-  if (a->C1 > 0 && (!a->A1 || (a->lda1 & 7))) return PMI_ERR_ARG;
-  if (a->taps != 1 && a->taps != 9) return PMI_ERR_ARG;
-  if (a->stride != 1 && a->stride != 2) return PMI_ERR_ARG;
-  if (a->K != a->taps * (a->C0 + a->C1)) return PMI_ERR_ARG;
-  if (a->R && (a->ldr & 3)) return PMI_ERR_ARG;
-  if (a->nbias && a->hw <= 0) return PMI_ERR_ARG;
+  if ((a->N & 3) && (a->bias || a->nbias || a->R || a->ldd < ((a->N + 3) & ~3))) return bad_arg(__LINE__);
+  if ((a->lda0 & 7) || (a->ldb & 7) || (a->ldd & 3)) return bad_arg(__LINE__);
+  if (a->C1 > 0 && (!a->A1 || (a->lda1 & 7))) return bad_arg(__LINE__);
+  if (a->taps != 1 && a->taps != 9) return bad_arg(__LINE__);
+  if (a->stride != 1 && a->stride != 2) return bad_arg(__LINE__);
+  if (a->K != a->taps * (a->C0 + a->C1)) return bad_arg(__LINE__);
+  if (a->R && (a->ldr & 3)) return bad_arg(__LINE__);
+  if (a->split_out && ((a->split_out != 8 && a->split_out != 32) || a->out_f32 || a->res_f32 || (a->N % a->split_out) || a->batch > 1 || a->pro_a)) return bad_arg(__LINE__);
+  if (a->split_in && a->pro_a) return bad_arg(__LINE__);
+  if (a->nbias && a->hw <= 0) return bad_arg(__LINE__);
   const bool conv = a->taps == 9 || a->up || a->stride == 2;
-  if (a->res_up && ((a->H & 1) || (a->W & 1))) return PMI_ERR_ARG;
-  if ((conv || a->res_up) && (a->H <= 0 || a->W <= 0 || a->Hin <= 0 || a->Win <= 0 || a->M % (a->H * a->W))) return PMI_ERR_ARG;
-  if (a->up && (a->H != 2 * a->Hin || a->W != 2 * a->Win)) return PMI_ERR_ARG;
-  if (a->batch > 1 && a->batch_inner <= 0) return PMI_ERR_ARG;
+  if (a->res_up && ((a->H & 1) || (a->W & 1))) return bad_arg(__LINE__);
+  if ((conv || a->res_up) && (a->H <= 0 || a->W <= 0 || a->Hin <= 0 || a->Win <= 0 || a->M % (a->H * a->W))) return bad_arg(__LINE__);
+  if (a->up && (a->H != 2 * a->Hin || a->W != 2 * a->Win)) return bad_arg(__LINE__);
+  if (a->batch > 1 && a->batch_inner <= 0) return bad_arg(__LINE__);
   const int halo = g_allow_halo ? pmi_conv3x3_halo_config(a) : -1;
   if (a->pro_a && (!a->pro_b || halo < 0)) return PMI_ERR_ARG;
   if (a->stats && a->stats_p != pmi_igemm_stats_rows(a)) return PMI_ERR_ARG;

@@ -23,14 +23,15 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const u16* __restrict__ x
   if (my_p < PPI) {
     for (int c8 = my_c; c8 < C8; c8 += TPP) {
       const bool second = c8 * 8 >= C0;
-      const u16* xb = second ? x1 + (int64_t)n * HW * C1 + (c8 * 8 - C0) : x + (int64_t)n * HW * C0 + c8 * 8;
-      const int ld = second ? C1 : C0;
+      const int Cs = second ? C1 : C0, cl = second ? c8 * 8 - C0 : c8 * 8;    // source tensor's channel count, channel inside it
+      const int ld = row_elems<T>(Cs);
+      const u16* xb = (second ? x1 : x) + (int64_t)n * HW * ld;
       float s[8], q[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
       for (int p = p0 + my_p; p < p1; p += PPI) {
         float f[8];
-        unpack8<T>(*(const uint4*)(xb + (int64_t)p * ld), f);
+        load8<T>(xb + (int64_t)p * ld, cl, Cs, f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
       }
@@ -133,9 +134,9 @@ __global__ __launch_bounds__(256) void gn_finalize2_kernel(const float* __restri
 }
 
 template <typename T>
-__device__ __forceinline__ void affine_act8(const u16* p, const float* a, const float* b, int act, float* out, float w) {
+__device__ __forceinline__ void affine_act8(const u16* row, int c, int C, const float* a, const float* b, int act, float* out, float w) {
   float f[8];
-  unpack8<T>(*(const uint4*)p, f);
+  load8<T>(row, c, C, f);
 #pragma unroll
   for (int e = 0; e < 8; ++e) out[e] += w * act_apply(f[e] * a[e] + b[e], act);
 }
@@ -160,26 +161,28 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const u16* __restrict__ x
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
     const bool second = c8 * 8 >= C0;
-    const u16* src = second ? x1 + (c8 * 8 - C0) : x + c8 * 8;
-    const int ld = second ? C - C0 : C0;
+    const u16* src = second ? x1 : x;
+    const int Cs = second ? C - C0 : C0, cl = second ? c8 * 8 - C0 : c8 * 8;
+    const int ld = row_elems<T>(Cs);
     if (POOL) {
       const int rem = (int)(pix - (int64_t)n * Ho * Wo);
       const int oy = rem / Wo, ox = rem - oy * Wo;
       const u16* base = src + (((int64_t)n * H + 2 * oy) * W + 2 * ox) * ld;
-      affine_act8<T>(base, a, b, act, o, 0.25f);
-      affine_act8<T>(base + ld, a, b, act, o, 0.25f);
-      affine_act8<T>(base + (int64_t)W * ld, a, b, act, o, 0.25f);
-      affine_act8<T>(base + (int64_t)W * ld + ld, a, b, act, o, 0.25f);
+      affine_act8<T>(base, cl, Cs, a, b, act, o, 0.25f);
+      affine_act8<T>(base + ld, cl, Cs, a, b, act, o, 0.25f);
+      affine_act8<T>(base + (int64_t)W * ld, cl, Cs, a, b, act, o, 0.25f);
+      affine_act8<T>(base + (int64_t)W * ld + ld, cl, Cs, a, b, act, o, 0.25f);
     } else {
-      affine_act8<T>(src + pix * ld, a, b, act, o, 1.f);
+      affine_act8<T>(src + pix * ld, cl, Cs, a, b, act, o, 1.f);
     }
+    const int ldy = row_elems<T>(C);
     if (res) {
       float r[8];
-      unpack8<T>(*(const uint4*)(res + pix * C + c8 * 8), r);
+      load8<T>(res + pix * ldy, c8 * 8, C, r);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] += r[e];
     }
-    *(uint4*)(y + pix * C + c8 * 8) = pack8<T>(o);
+    store8<T>(y + pix * ldy, c8 * 8, C, o);
   }
 }
 
@@ -196,6 +199,7 @@ extern "C" int pmi_gn_stats(const void* x, const void* x1, int C0, float* ws, in
   if (!x || !ws || N <= 0 || HW <= 0 || C <= 0 || (C & 7) || C > MAXC || G <= 0 || C % G || nchunk <= 0) return PMI_ERR_ARG;
   dim3 grid(nchunk, N), block(256);
   if (dtype == PMI_DT_BF16) hipLaunchKernelGGL(gn_stats_kernel<BF16>, grid, block, 0, (hipStream_t)s, (const u16*)x, (const u16*)x1, C0, ws, HW, C, G, nchunk);
+  else if (dtype == PMI_DT_F16X2) hipLaunchKernelGGL(gn_stats_kernel<F16X2>, grid, block, 0, (hipStream_t)s, (const u16*)x, (const u16*)x1, C0, ws, HW, C, G, nchunk);
   else hipLaunchKernelGGL(gn_stats_kernel<F16>, grid, block, 0, (hipStream_t)s, (const u16*)x, (const u16*)x1, C0, ws, HW, C, G, nchunk);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
@@ -238,6 +242,7 @@ extern "C" int pmi_gn_apply(const void* x, const void* x1, int C0, const float* 
   hipStream_t st = (hipStream_t)s;
 #define GO(TT, PP) hipLaunchKernelGGL((gn_apply_kernel<TT, PP>), grid, block, 0, st, (const u16*)x, (const u16*)x1, C0, coef_a, coef_b, (const u16*)res, (u16*)y, N, H, W, C, act)
   if (dtype == PMI_DT_BF16) { if (pool) GO(BF16, true); else GO(BF16, false); }
+  else if (dtype == PMI_DT_F16X2) { if (pool) GO(F16X2, true); else GO(F16X2, false); }
   else { if (pool) GO(F16, true); else GO(F16, false); }
 #undef GO
   PMI_CHECK_LAUNCH();

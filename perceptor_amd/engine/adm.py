@@ -58,8 +58,9 @@ def pixelart_config() -> AdmConfig:     # create_models.py:36-62
 
 
 class _Res:
-    def __init__(self, prefix, cin, cout, up=False, down=False):
+    def __init__(self, prefix, cin, cout, up=False, down=False, srcs=None):
         self.p, self.cin, self.cout, self.up, self.down = prefix, cin, cout, up, down
+        self.srcs = srcs          # channel counts of a concat input (h, skip), None for a single source
         self.emb_off = 0
 
 
@@ -113,7 +114,7 @@ def build_plan(cfg: AdmConfig):
             j = len(out)
             ich = skip_ch.pop()
             cout = int(mc * mult)
-            layers = [_Res(f"output_blocks.{j}.0", ch + ich, cout)]
+            layers = [_Res(f"output_blocks.{j}.0", ch + ich, cout, srcs=(ch, ich))]
             ch = cout
             k = 1
             if ds in cfg.attention_ds:
@@ -172,7 +173,11 @@ class AdmEngine:
         f32 = lambda k: sd[k].detach().float().to(dev).contiguous()
         lin = lambda k, **kw: PackedLinear(sd[k + ".weight"], sd.get(k + ".bias"), dt, dev, **kw)
         self.w: Dict[str, object] = {}
-        self.te0, self.te2 = lin("time_embed.0"), lin("time_embed.2")
+        self.precise = dt == _hip.DT_F16X2
+        if self.precise:      # fp32 time MLPs (exact-fp32 MFMA GEMM): their weights stay fp32 in the reference too (unet.py:610-616)
+            self.te0, self.te2 = (f32("time_embed.0.weight"), f32("time_embed.0.bias")), (f32("time_embed.2.weight"), f32("time_embed.2.bias"))
+        else:
+            self.te0, self.te2 = lin("time_embed.0"), lin("time_embed.2")
         emb_w, emb_b, off = [], [], 0
         for layers in self.inp + [self.mid] + self.out:
             for l in layers:
@@ -181,11 +186,11 @@ class AdmEngine:
                 elif isinstance(l, _Res):
                     p = l.p
                     self.w[p + ".gn1"] = (f32(p + ".in_layers.0.weight"), f32(p + ".in_layers.0.bias"))
-                    self.w[p + ".conv1"] = lin(p + ".in_layers.2")
+                    self.w[p + ".conv1"] = lin(p + ".in_layers.2", sources=l.srcs)
                     self.w[p + ".gn2"] = (f32(p + ".out_layers.0.weight"), f32(p + ".out_layers.0.bias"))
                     self.w[p + ".conv2"] = lin(p + ".out_layers.3")
                     if l.cin != l.cout:
-                        self.w[p + ".skip"] = lin(p + ".skip_connection")
+                        self.w[p + ".skip"] = lin(p + ".skip_connection", sources=l.srcs)
                     l.emb_off = off
                     emb_w.append(sd[p + ".emb_layers.1.weight"].float()); emb_b.append(sd[p + ".emb_layers.1.bias"].float())
                     off += emb_w[-1].shape[0]
@@ -196,7 +201,10 @@ class AdmEngine:
                     self.w[p + ".proj"] = lin(p + ".proj_out")
                 elif isinstance(l, _Resample) and cfg.conv_resample:
                     self.w[l.p] = lin(l.p + (".conv" if l.up else ".op"))
-        self.emb_all = PackedLinear(torch.cat(emb_w, 0), torch.cat(emb_b, 0), dt, dev)
+        if self.precise:
+            self.emb_all = (torch.cat(emb_w, 0).to(dev).contiguous(), torch.cat(emb_b, 0).to(dev).contiguous())
+        else:
+            self.emb_all = PackedLinear(torch.cat(emb_w, 0), torch.cat(emb_b, 0), dt, dev)
         self.gn_out = (f32("out.0.weight"), f32("out.0.bias"))
         self.conv_out = lin("out.2")
 
@@ -267,12 +275,17 @@ class AdmEngine:
         n, _, hh, ww = images.shape
         t = timesteps.to(device=dev, dtype=torch.float32).contiguous()
         tdt = _hip.TORCH_DTYPE[dt]
-        temb = torch.empty((n, cfg.model_channels), dtype=tdt, device=dev)
+        temb = torch.empty((n, cfg.model_channels), dtype=torch.float32 if self.precise else tdt, device=dev)
         call("pmi_timestep_embedding", ptr(t), ptr(temb), n, cfg.model_channels, 10000.0, dt)
-        e = ops.igemm(temb, self.te0, act=ACT_SILU)
-        e = ops.igemm(e, self.te2, act=ACT_SILU)            # = SiLU(emb): the only form the ResBlocks consume
-        emb = ops.igemm(e, self.emb_all, out_f32=True)       # [N, sum of all emb_layers outputs]
-        x = torch.empty((n, hh, ww, 8), dtype=tdt, device=dev)
+        if self.precise:
+            e = ops.linear_f32(temb, *self.te0, act=ACT_SILU)
+            e = ops.linear_f32(e, *self.te2, act=ACT_SILU)
+            emb = ops.linear_f32(e, *self.emb_all)
+        else:
+            e = ops.igemm(temb, self.te0, act=ACT_SILU)
+            e = ops.igemm(e, self.te2, act=ACT_SILU)            # = SiLU(emb): the only form the ResBlocks consume
+            emb = ops.igemm(e, self.emb_all, out_f32=True)       # [N, sum of all emb_layers outputs]
+        x = torch.empty((n, hh, ww, 16 if self.precise else 8), dtype=tdt, device=dev)
         call("pmi_prep_input", ptr(images), None, 0, ptr(x), n, hh, ww, 8, dt)
         h, hs = x, []
         for layers in self.inp:

@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 from .. import _hip
-from .._hip import ACT_NONE, IgemmArgs, call, ptr
+from .._hip import ACT_NONE, DT_F16X2, IgemmArgs, call, ptr
 
 
 HALO_ENABLED = True
@@ -37,10 +37,27 @@ def _empty(shape, dtype, device):
     return torch.empty(shape, dtype=dtype, device=device)
 
 
-class PackedLinear:
-    """Weights packed for pmi_igemm: B[Npad][K] 16-bit with k = tap*Cin + c, fp32 bias."""
+def split_group(c: int) -> int:
+    """Group size of a precise (hi + lo) tensor with c logical channels (csrc/common.h: F16X2)."""
+    if c % 32 == 0:
+        return 32
+    if c > 32 or c % 8:
+        raise ValueError(f"precise tensors need a channel count that is a multiple of 32 (or of 8 below 32), got {c}")
+    return c
 
-    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], dt: int, device, cin_pad: Optional[int] = None):
+
+def logical_c(x: torch.Tensor, dt: int) -> int:
+    return x.shape[-1] // 2 if dt == DT_F16X2 else x.shape[-1]
+
+
+class PackedLinear:
+    """Weights packed for pmi_igemm: B[Npad][K] 16-bit with k = tap*Cin + c, fp32 bias.
+
+    dt = precise (DT_F16X2): the inputs are hi + lo tensors with 2*Cin channels per pixel ([hi G | lo G] per group of G channels), so
+    the f16 weights are duplicated along K in the same pattern: W*hi + W*lo accumulates in fp32 on the MFMA.  `sources` gives the
+    logical channel counts of a two-pointer concat input (each source is its own precise tensor with its own grouping)."""
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], dt: int, device, cin_pad: Optional[int] = None, sources=None):
         w = weight.detach().float()
         if w.ndim == 3:   # Conv1d k=1
             w = w[..., 0]
@@ -52,6 +69,18 @@ class PackedLinear:
         self.n_p = (cout + 3) // 4 * 4
         packed = torch.zeros(self.n_p, kh * kw, self.cin_p, dtype=torch.float32)
         packed[:cout, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+        self.split = dt == DT_F16X2
+        self.cin_l = self.cin_p                      # logical input channels
+        if self.split:
+            parts, o = [], 0
+            for cs in (sources or [self.cin_p]):
+                g = split_group(cs)
+                blk = packed[:, :, o:o + cs].reshape(self.n_p, kh * kw, cs // g, 1, g).expand(-1, -1, -1, 2, -1)
+                parts.append(blk.reshape(self.n_p, kh * kw, 2 * cs))
+                o += cs
+            assert o == self.cin_p
+            packed = torch.cat(parts, dim=2)
+            self.cin_p = 2 * self.cin_p              # channels of the (physical) input tensors
         self.w = packed.reshape(self.n_p, -1).to(device=device, dtype=_hip.TORCH_DTYPE[dt]).contiguous()
         self.b = None
         if bias is not None:
@@ -103,6 +132,11 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
         m = a0.shape[0]
         a.hw = hw or 1
         oshape = (m, lin.n_p)
+    if lin.split:
+        a.split_in = 1
+        if not out_f32:                                   # precise output: hi + lo pairs, 2*N 16-bit values per row
+            a.split_out = split_group(lin.n_p)
+            oshape = oshape[:-1] + (2 * lin.n_p,)
     if out is None:
         out = _empty(oshape, torch.float32 if out_f32 else _hip.TORCH_DTYPE[dt], a0.device)
     a.A0, a.A1, a.B = ptr(a0), ptr(a1), ptr(lin.w)
@@ -125,12 +159,13 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
         a.Bf = ptr(lin.frag(64 if cfg == 4 else 32)) if cfg in (4, 5) else None
     if prologue is not None:
         ca, cb, pact = prologue
-        if HALO_ENABLED and _hip.lib().pmi_conv3x3_halo_config(C.byref(a)) >= 0:
+        if HALO_ENABLED and not lin.split and _hip.lib().pmi_conv3x3_halo_config(C.byref(a)) >= 0:
             a.pro_a, a.pro_b, a.pro_act = ptr(ca), ptr(cb), pact
         else:   # not eligible: materialise act(x*a+b) with the streaming kernel, then convolve
             n_, h_, w_, _ = a0.shape
             y = _empty((n_, h_, w_, c0 + c1), a0.dtype, a0.device)
-            call("pmi_gn_apply", ptr(a0), ptr(a1), c0, ptr(ca), ptr(cb), None, ptr(y), n_, h_, w_, c0 + c1, pact, 0, dt)
+            lc0, lc = (c0 // 2, (c0 + c1) // 2) if lin.split else (c0, c0 + c1)       # logical channel counts
+            call("pmi_gn_apply", ptr(a0), ptr(a1), lc0, ptr(ca), ptr(cb), None, ptr(y), n_, h_, w_, lc, pact, 0, dt)
             a.A0, a.A1, a.C0, a.C1, a.lda0, a.lda1 = ptr(y), None, c0 + c1, 0, c0 + c1, 0
             a0 = y
     if SPLITK_ENABLED:
@@ -203,8 +238,9 @@ def bgemm(A: torch.Tensor, B: torch.Tensor, D: torch.Tensor, *, M: int, N: int, 
 
 
 def _gn_coeffs(x, x1, gamma, beta, groups, dt, film, film_ld, eps):
-    n, h, w, c0 = x.shape
-    c1 = x1.shape[-1] if x1 is not None else 0
+    n, h, w, _ = x.shape
+    c0 = logical_c(x, dt)
+    c1 = logical_c(x1, dt) if x1 is not None else 0
     c, hw, dev = c0 + c1, h * w, x.device
     ca = _empty((n, c), torch.float32, dev)
     cb = _empty((n, c), torch.float32, dev)
@@ -232,10 +268,12 @@ def group_norm(x: torch.Tensor, gamma, beta, groups: int, dt: int, *, x1: Option
                film: Optional[torch.Tensor] = None, film_ld: int = 0, residual: Optional[torch.Tensor] = None,
                act: int = ACT_NONE, pool: bool = False, eps: float = 1e-5) -> torch.Tensor:
     """GroupNorm over the channel-concat of x (and x1) -> act(norm * gamma + beta [FiLM]) [-> 2x2 avg pool] [+ residual]."""
-    n, h, w, c0 = x.shape
-    c = c0 + (x1.shape[-1] if x1 is not None else 0)
+    n, h, w, _ = x.shape
+    c0 = logical_c(x, dt)
+    c = c0 + (logical_c(x1, dt) if x1 is not None else 0)
     ca, cb = _gn_coeffs(x, x1, gamma, beta, groups, dt, film, film_ld, eps)
-    y = _empty((n, h // 2, w // 2, c) if pool else (n, h, w, c), x.dtype, x.device)
+    cphys = 2 * c if dt == DT_F16X2 else c
+    y = _empty((n, h // 2, w // 2, cphys) if pool else (n, h, w, cphys), x.dtype, x.device)
     call("pmi_gn_apply", ptr(x), ptr(x1), c0, ptr(ca), ptr(cb), ptr(residual), ptr(y), n, h, w, c, act, int(pool), dt)
     return y
 
@@ -243,14 +281,14 @@ def group_norm(x: torch.Tensor, gamma, beta, groups: int, dt: int, *, x1: Option
 def avgpool2(x: torch.Tensor, dt: int) -> torch.Tensor:
     n, h, w, c = x.shape
     y = _empty((n, h // 2, w // 2, c), x.dtype, x.device)
-    call("pmi_avgpool2", ptr(x), ptr(y), n, h, w, c, dt)
+    call("pmi_avgpool2", ptr(x), ptr(y), n, h, w, logical_c(x, dt), dt)
     return y
 
 
 def upsample_bilinear2(x: torch.Tensor, dt: int) -> torch.Tensor:
     n, h, w, c = x.shape
     y = _empty((n, h * 2, w * 2, c), x.dtype, x.device)
-    call("pmi_upsample_bilinear2", ptr(x), ptr(y), n, h, w, c, dt)
+    call("pmi_upsample_bilinear2", ptr(x), ptr(y), n, h, w, logical_c(x, dt), dt)
     return y
 
 
@@ -267,6 +305,8 @@ def attention(qkv: torch.Tensor, heads: int, order: int, dt: int) -> torch.Tenso
     order 0: channels = (head, {q,k,v}, d) (unet.py:332-348); order 1: ({q,k,v}, head, d).
     Head dim 64 runs the fused flash kernel; other head dims use batched MFMA GEMMs + softmax.
     """
+    if dt == DT_F16X2:
+        return attention_precise(qkv, heads, order)
     n, t, c3 = qkv.shape
     c = c3 // 3
     d = c // heads
@@ -296,4 +336,53 @@ def attention(qkv: torch.Tensor, heads: int, order: int, dt: int) -> torch.Tenso
     call("pmi_transpose_16", qkv.data_ptr() + vo * qkv.element_size(), ptr(vt), t, d, c3, t * c3, hs, heads, n * heads)
     bgemm(p, vt, out, M=t, N=d, K=tp, lda=tp, ldb=tp, ldd=c, batch=n * heads, batch_inner=heads,
           sA=(heads * t * tp, t * tp), sB=(heads * d * tp, d * tp), sD=(t * c, d), dt=dt)
+    return out
+
+
+def gemm_f32(A: torch.Tensor, B: torch.Tensor, D: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldb: int, ldd: int, trans_b: bool = False,
+             bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, alpha: float = 1.0, batch: int = 1, batch_inner: int = 1,
+             sA=(0, 0), sB=(0, 0), sD=(0, 0), a_off: int = 0, b_off: int = 0, d_off: int = 0) -> torch.Tensor:
+    """Exact-fp32 batched GEMM on the f32-input MFMA (csrc/f32gemm.hip): D[z] = act(alpha * A[z] @ B[z]^T + bias)."""
+    a = _hip.GemmF32Args()
+    a.A, a.B, a.bias, a.D = A.data_ptr() + 4 * a_off, B.data_ptr() + 4 * b_off, ptr(bias), D.data_ptr() + 4 * d_off
+    a.M, a.N, a.K, a.lda, a.ldb, a.ldd = M, N, K, lda, ldb, ldd
+    a.transB, a.act, a.alpha, a.batch, a.batch_inner = int(trans_b), act, alpha, batch, batch_inner
+    a.sA_o, a.sA_i = sA
+    a.sB_o, a.sB_i = sB
+    a.sD_o, a.sD_i = sD
+    call("pmi_gemm_f32", C.byref(a))
+    return D
+
+
+def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE) -> torch.Tensor:
+    """fp32 linear layer x [M, K] @ weight [N, K]^T + bias (the time MLPs in precise mode)."""
+    m, k = x.shape
+    n = weight.shape[0]
+    out = _empty((m, n), torch.float32, x.device)
+    return gemm_f32(x, weight, out, M=m, N=n, K=k, lda=x.stride(0), ldb=weight.stride(0), ldd=n, bias=bias, act=act)
+
+
+def attention_precise(qkv: torch.Tensor, heads: int, order: int) -> torch.Tensor:
+    """Self-attention in precise mode: qkv is a precise tensor [N, T, 2*3C]; scores, softmax and values in exact fp32
+    (both operands of these products are activations, so the hi + lo weight trick does not apply); returns a precise [N, T, 2C]."""
+    n, t, c6 = qkv.shape
+    c3 = c6 // 2
+    c = c3 // 3
+    d = c // heads
+    dev = qkv.device
+    q32 = _empty((n, t, c3), torch.float32, dev)
+    call("pmi_split_to_f32", ptr(qkv), ptr(q32), n * t, c3)
+    if order == 0:
+        qo, ko, vo, hs = 0, d, 2 * d, 3 * d
+    else:
+        qo, ko, vo, hs = 0, c, 2 * c, d
+    s = _empty((n * heads, t, t), torch.float32, dev)
+    gemm_f32(q32, q32, s, M=t, N=t, K=d, lda=c3, ldb=c3, ldd=t, batch=n * heads, batch_inner=heads,
+             sA=(t * c3, hs), sB=(t * c3, hs), sD=(heads * t * t, t * t), a_off=qo, b_off=ko)
+    call("pmi_softmax_f32", ptr(s), n * heads * t, t, t, float(d) ** -0.5)
+    o32 = _empty((n, t, c), torch.float32, dev)
+    gemm_f32(s, q32, o32, M=t, N=d, K=t, lda=t, ldb=c3, ldd=c, trans_b=True, batch=n * heads, batch_inner=heads,
+             sA=(heads * t * t, t * t), sB=(t * c3, hs), sD=(t * c, d), b_off=vo)
+    out = _empty((n, t, 2 * c), torch.float16, dev)
+    call("pmi_split_from_f32", ptr(o32), c, ptr(out), n * t, c)
     return out

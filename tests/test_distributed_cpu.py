@@ -72,3 +72,22 @@ def test_shard_ranges_cover_and_balance():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` without a torch.distributed.run environment starts its own ranks (the driver's invocation):
+    --rehearse runs only the process-group plumbing (gloo on this GPU-less box), rank 0 prints the JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["all_gather_ok"] is True
+    # a rank whose WORLD_SIZE disagrees with --gpus is rejected instead of silently benchmarking another layout
+    env["WORLD_SIZE"] = "3"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "does not match" in (r.stderr + r.stdout)
