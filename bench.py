@@ -28,7 +28,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0}   # dense MFMA peak, MI355X_MICROARCH.md (never the 2:1-sparse figure)
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "precise": 2500.0}   # precise = f16 MFMA on hi + lo pairs: twice the MFMA work per algorithmic FLOP   # dense MFMA peak, MI355X_MICROARCH.md (never the 2:1-sparse figure)
 
 # forward GFLOP / sample (torch flop counter on the reference modules)
 UNET_GFLOP = {"standard": {512: 3964.7, 256: 989.0}, "pixelart": {256: 497.5, 64: 497.5 / 16},
@@ -52,7 +52,8 @@ def parse():
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--config", default="c5", choices=sorted(CONFIGS))
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "precise"],
+                   help="UNet arithmetic: bf16 / f16 single-pass MFMA, or precise (hi + lo f16 pairs, eps max-abs error < 1e-3 vs the fp32 reference)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-events", action="store_true")
     p.add_argument("--lt-margin", type=int, default=None, help="percent a hipBLASLt candidate must beat the heuristic pick by to replace it (A/B)")

@@ -99,6 +99,7 @@ typedef struct {
   float alpha;
   int32_t batch, batch_inner;          /* grid.z batches: z -> (z / batch_inner, z % batch_inner) */
   int64_t sA_o, sA_i, sB_o, sB_i, sD_o, sD_i;
+  const float* R;                      /* optional residual added after the activation, laid out like D */
 } pmi_gemm_f32_args;
 int pmi_gemm_f32(const pmi_gemm_f32_args* a, pmi_stream_t stream);
 int pmi_softmax_f32(float* S, int rows, int T, int ld, float scale, pmi_stream_t s);   /* in place, fp32 (unet.py:346) */

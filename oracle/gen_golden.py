@@ -115,6 +115,28 @@ def gen_adm():
         save(f"adm_{name}_{res}", x=x, t=t, y_sub=y[:, :, ::4, ::4].contiguous(), y_mom=moments(y))
 
 
+def gen_adm_fp16w():
+    """Weights as a real checkpoint has them: full-precision fp32 values, of which the reference's own convert_to_fp16()
+    (unet.py:610-616, fp16_util.py:16-23) casts the torso convolutions to fp16 -- NOT bf16-representable, so packing them to bf16
+    loses 3 mantissa bits, and the fp32 time / output layers are not representable in either 16-bit type.  The names of the
+    tensors the reference rounded are stored with the fixture (data, so the test can apply the same rounding)."""
+    su = R.ref("models.guided_diffusion.script_util")
+    kw = ADM_TINY["a"]
+    m = su.create_model(**kw).eval()
+    raw = synth_like(m.state_dict(), 0, rounding="none")
+    m.load_state_dict(raw)
+    m.convert_to_fp16()
+    rounded = [k for k, v in m.state_dict().items() if v.dtype == torch.float16]
+    m.convert_to_fp32()
+    m.dtype = torch.float32          # run the fp16-VALUED weights in fp32 arithmetic (CPU oracle of the GPU path's weights)
+    x = seeded_noise((2, 3, 64, 64), 31)
+    t = torch.tensor([10, 500])
+    with torch.no_grad():
+        y = m(x, t)
+    chk = {k: float(v.double().abs().sum()) for k, v in m.state_dict().items()}
+    save("adm_tiny_a_fp16w", x=x, t=t, y=y, rounded_keys=np.array(rounded), weight_abs_sum=np.array([chk[k] for k in sorted(chk)]))
+
+
 def gen_vdiff():
     y2 = R.ref("models.velocity_diffusion.yfcc_2")
     cc = R.ref("models.velocity_diffusion.cc12m_1")
@@ -175,6 +197,11 @@ def gen_clip():
         save(f"clip_vit_{tag}", img=img.detach(), probe=probe, emb=e.detach(), emb_n=en.detach(),
              grad_sub=g[:, :, ::4, ::4].contiguous(), grad_mom=moments(g))
 
+
+if __name__ == "__main__" and len(sys.argv) > 1:
+    for name in sys.argv[1:]:
+        globals()["gen_" + name]()
+    sys.exit(0)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["sampling", "adm", "vdiff", "clip"]

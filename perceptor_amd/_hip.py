@@ -50,7 +50,7 @@ class GemmF32Args(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("bias", C.c_void_p), ("D", C.c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldd", C.c_int32),
                 ("transB", C.c_int32), ("act", C.c_int32), ("alpha", C.c_float), ("batch", C.c_int32), ("batch_inner", C.c_int32),
-                ("sA_o", C.c_int64), ("sA_i", C.c_int64), ("sB_o", C.c_int64), ("sB_i", C.c_int64), ("sD_o", C.c_int64), ("sD_i", C.c_int64)]
+                ("sA_o", C.c_int64), ("sA_i", C.c_int64), ("sB_o", C.c_int64), ("sB_i", C.c_int64), ("sD_o", C.c_int64), ("sD_i", C.c_int64), ("R", C.c_void_p)]
 
 
 _lib = None

@@ -2,7 +2,7 @@
 // 16-bit MFMA rate) and an in-place fp32 row softmax.  Used only where "precise" mode (dtype 2) needs full fp32 products of
 // two ACTIVATION operands -- the UNet's attention scores / values (0.3 % of its FLOPs) -- and for the tiny fp32 time MLPs;
 // everything weight-shaped runs on the f16 MFMA with hi + lo activation pairs (common.h: F16X2).
-//   D[b][m][n] = act(alpha * sum_k A[b][m][k] * B[b][n][k] (or B[b][k][n] when transB) + bias[n])
+//   D[b][m][n] = act(alpha * sum_k A[b][m][k] * B[b][n][k] (or B[b][k][n] when transB) + bias[n]) + R[b][m][n]
 // Workgroup tile 64 x 64, 4 waves x one 32 x 32 block, K staged 32 at a time through LDS (rows padded to 33 floats).
 #include "common.h"
 #include "../../include/perceptor_hip.h"
@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const pmi_gemm_f32_args a
       float v = acc[4 * g + e] * a.alpha;
       if (a.bias) v += a.bias[n];
       if (a.act != PMI_ACT_NONE) v = act_apply(v, a.act);
+      if (a.R) v += a.R[zo * a.sD_o + zi * a.sD_i + (int64_t)m * a.ldd + n];      // residual: D's layout
       D[(int64_t)m * a.ldd + n] = v;
     }
 }

@@ -71,16 +71,34 @@ class PackedLinear:
         packed[:cout, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
         self.split = dt == DT_F16X2
         self.cin_l = self.cin_p                      # logical input channels
+        self.self_concat = False
         if self.split:
-            parts, o = [], 0
-            for cs in (sources or [self.cin_p]):
-                g = split_group(cs)
-                blk = packed[:, :, o:o + cs].reshape(self.n_p, kh * kw, cs // g, 1, g).expand(-1, -1, -1, 2, -1)
-                parts.append(blk.reshape(self.n_p, kh * kw, 2 * cs))
-                o += cs
-            assert o == self.cin_p
-            packed = torch.cat(parts, dim=2)
-            self.cin_p = 2 * self.cin_p              # channels of the (physical) input tensors
+            def dup(wt, lo_zero=False):              # [N, taps, C] -> [N, taps, 2C] in the [hi G | lo G] pattern of the input
+                parts, o = [], 0
+                for cs in (sources or [self.cin_l]):
+                    g = split_group(cs)
+                    blk = wt[:, :, o:o + cs].reshape(self.n_p, kh * kw, cs // g, 1, g).expand(-1, -1, -1, 2, -1).clone()
+                    if lo_zero:
+                        blk[:, :, :, 1, :] = 0
+                    parts.append(blk.reshape(self.n_p, kh * kw, 2 * cs))
+                    o += cs
+                assert o == self.cin_l
+                return torch.cat(parts, dim=2)
+            w_hi = packed.to(torch.float16).float()
+            w_lo = packed - w_hi                     # what f16 cannot hold of fp32 weights (zero for fp16 checkpoints / the synthetic weights)
+            packed = dup(w_hi)
+            self.cin_p = 2 * self.cin_l              # channels of the (physical) input tensors
+            # f16 holds the weights to within the mode's own precision (~2^-22 of the largest weight; tiny values below the f16
+            # subnormal grid lose < 6e-8 absolute): nothing to add.  Otherwise the low part becomes a second K block.
+            if float(w_lo.abs().max()) > 2.0 ** -22 * float(packed.abs().max()):
+                if sources is not None:
+                    import warnings
+                    warnings.warn("precise mode: fp32 weights of a two-source (concat) convolution are rounded to f16")
+                else:
+                    # second K block over the SAME input tensor (passed again as the second source): W_lo * x_hi
+                    packed = torch.cat([packed, dup(w_lo, lo_zero=True)], dim=2)
+                    self.self_concat = True
+                    self.cin_p = 2 * self.cin_p
         self.w = packed.reshape(self.n_p, -1).to(device=device, dtype=_hip.TORCH_DTYPE[dt]).contiguous()
         self.b = None
         if bias is not None:
@@ -117,7 +135,7 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
     conv = a0.ndim == 4
     c0 = a0.shape[-1]
     c1 = a1.shape[-1] if a1 is not None else 0
-    assert c0 + c1 == lin.cin_p, (c0, c1, lin.cin_p)
+    assert (c0 + c1) * (2 if lin.self_concat else 1) == lin.cin_p, (c0, c1, lin.cin_p)
     a = IgemmArgs()
     if conv:
         n, hin, win, _ = a0.shape
@@ -168,6 +186,9 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
             call("pmi_gn_apply", ptr(a0), ptr(a1), lc0, ptr(ca), ptr(cb), None, ptr(y), n_, h_, w_, lc, pact, 0, dt)
             a.A0, a.A1, a.C0, a.C1, a.lda0, a.lda1 = ptr(y), None, c0 + c1, 0, c0 + c1, 0
             a0 = y
+    if lin.self_concat:        # precise mode, fp32 weights: their low part multiplies the SAME input again as a second source
+        assert a.A1 is None
+        a.A1, a.C1, a.lda1 = a.A0, a.C0, a.lda0
     if SPLITK_ENABLED:
         sk = _hip.lib().pmi_igemm_splitk(C.byref(a))
         if sk > 1:   # few output tiles, long K: split the reduction over grid.z into fp32 slabs
@@ -341,7 +362,7 @@ def attention(qkv: torch.Tensor, heads: int, order: int, dt: int) -> torch.Tenso
 
 def gemm_f32(A: torch.Tensor, B: torch.Tensor, D: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldb: int, ldd: int, trans_b: bool = False,
              bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, alpha: float = 1.0, batch: int = 1, batch_inner: int = 1,
-             sA=(0, 0), sB=(0, 0), sD=(0, 0), a_off: int = 0, b_off: int = 0, d_off: int = 0) -> torch.Tensor:
+             sA=(0, 0), sB=(0, 0), sD=(0, 0), a_off: int = 0, b_off: int = 0, d_off: int = 0, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Exact-fp32 batched GEMM on the f32-input MFMA (csrc/f32gemm.hip): D[z] = act(alpha * A[z] @ B[z]^T + bias)."""
     a = _hip.GemmF32Args()
     a.A, a.B, a.bias, a.D = A.data_ptr() + 4 * a_off, B.data_ptr() + 4 * b_off, ptr(bias), D.data_ptr() + 4 * d_off
@@ -350,16 +371,18 @@ def gemm_f32(A: torch.Tensor, B: torch.Tensor, D: torch.Tensor, *, M: int, N: in
     a.sA_o, a.sA_i = sA
     a.sB_o, a.sB_i = sB
     a.sD_o, a.sD_i = sD
+    a.R = ptr(residual)
     call("pmi_gemm_f32", C.byref(a))
     return D
 
 
-def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE) -> torch.Tensor:
+def linear_f32(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE,
+               residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32 linear layer x [M, K] @ weight [N, K]^T + bias (the time MLPs in precise mode)."""
     m, k = x.shape
     n = weight.shape[0]
     out = _empty((m, n), torch.float32, x.device)
-    return gemm_f32(x, weight, out, M=m, N=n, K=k, lda=x.stride(0), ldb=weight.stride(0), ldd=n, bias=bias, act=act)
+    return gemm_f32(x, weight, out, M=m, N=n, K=k, lda=x.stride(0), ldb=weight.stride(0), ldd=n, bias=bias, act=act, residual=residual)
 
 
 def attention_precise(qkv: torch.Tensor, heads: int, order: int) -> torch.Tensor:

@@ -28,6 +28,7 @@ class Res:
     def __init__(self, cin, cmid, cout, last=False):
         self.cin, self.cmid, self.cout, self.last = cin, cmid, cout, last
         self.mod1 = self.mod2 = 0
+        self.srcs = None          # (c, c) when the block reads the concat a SkipBlock leaves behind
 
 
 class Attn:
@@ -112,6 +113,8 @@ def _walk(prog, prefix, fn):
         p = f"{prefix}.{i}"
         if isinstance(l, Skip):
             _walk(l.main, p + ".main", fn)
+            if i + 1 < len(prog) and isinstance(prog[i + 1], Res):
+                prog[i + 1].srcs = (prog[i + 1].cin // 2, prog[i + 1].cin // 2)
         else:
             fn(l, p)
 
@@ -156,6 +159,7 @@ class VDiffEngine:
         _hip.lib()
         sd, dev, dt = state_dict, self.device, self.dt
         self.cond = spec["cond"]
+        self.precise = dt == _hip.DT_F16X2
         f32 = lambda k: sd[k].detach().float().to(dev).contiguous()
         self.w: Dict[str, object] = {}
         mods, off = [], [0]
@@ -165,11 +169,11 @@ class VDiffEngine:
             if isinstance(l, Res):
                 j = 4 if self.cond else 2
                 self.w[p + ".c1"] = PackedLinear(sd[p + ".main.0.weight"], sd[p + ".main.0.bias"], dt, dev,
-                                                 cin_pad=24 if first[0] else None)
+                                                 cin_pad=24 if first[0] else None, sources=l.srcs)
                 first[0] = False
                 self.w[p + ".c2"] = PackedLinear(sd[p + f".main.{j}.weight"], sd[p + f".main.{j}.bias"], dt, dev)
                 if l.cin != l.cout:
-                    self.w[p + ".skip"] = PackedLinear(sd[p + ".skip.weight"], None, dt, dev, cin_pad=24 if l.cin == 19 else None)
+                    self.w[p + ".skip"] = PackedLinear(sd[p + ".skip.weight"], None, dt, dev, cin_pad=24 if l.cin == 19 else None, sources=l.srcs)
                 if self.cond:
                     l.mod1 = off[0]; mods.append(sd[p + ".main.2.layer.weight"].float()); off[0] += 2 * l.cmid
                     if not l.last:
@@ -183,9 +187,13 @@ class VDiffEngine:
         _walk(spec["net"], "net", pack)
         self.tw = f32("timestep_embed.weight").reshape(-1)
         if self.cond:
-            self.mod_all = PackedLinear(torch.cat(mods, 0), None, dt, dev)
             self.mtw = f32("mapping_timestep_embed.weight").reshape(-1)
-            L = lambda k, bias=True: PackedLinear(sd[k + ".weight"], sd.get(k + ".bias") if bias else None, dt, dev)
+            if self.precise:      # the mapping network runs in exact fp32 (tiny GEMMs)
+                self.mod_all = torch.cat(mods, 0).to(dev).contiguous()
+                L = lambda k, bias=True: (f32(k + ".weight"), f32(k + ".bias") if bias else None)
+            else:
+                self.mod_all = PackedLinear(torch.cat(mods, 0), None, dt, dev)
+                L = lambda k, bias=True: PackedLinear(sd[k + ".weight"], sd.get(k + ".bias") if bias else None, dt, dev)
             self.m = dict(a0=L("mapping.0.main.0"), a2=L("mapping.0.main.2"), askip=L("mapping.0.skip", False),
                           b0=L("mapping.1.main.0"), b2=L("mapping.1.main.2"))
 
@@ -194,7 +202,8 @@ class VDiffEngine:
         dt, w = self.dt, self.w
         skip = x
         if l.cin != l.cout:
-            skip = ops.igemm(x, w[p + ".skip"], a1=x1)
+            # precise mode: the last block's 3-channel skip stays fp32 (a 4-channel row cannot hold hi + lo groups)
+            skip = ops.igemm(x, w[p + ".skip"], a1=x1, out_f32=self.precise and l.last)
         elif x1 is not None:
             raise NotImplementedError("identity skip over a concatenated input does not occur in this model family")
         if not self.cond:
@@ -220,7 +229,7 @@ class VDiffEngine:
             g, b = w[p + ".gn"]
             hn = ops.group_norm(x, g, b, 1, dt)
         qkv = ops.igemm(hn.view(n * hh * ww, c), w[p + ".qkv"])
-        a = ops.attention(qkv.view(n, hh * ww, 3 * c), c // self.spec.get("head_dim", 64), 1, dt)
+        a = ops.attention(qkv.view(n, hh * ww, 3 * c), ops.logical_c(x, dt) // self.spec.get("head_dim", 64), 1, dt)
         return ops.igemm(a.view(n * hh * ww, c), w[p + ".out"], residual=x.view(n * hh * ww, c)).view(n, hh, ww, c)
 
     def _run(self, prog, prefix, x, mod):
@@ -252,6 +261,15 @@ class VDiffEngine:
         call("pmi_l2norm_rows", ptr(ce), ptr(cen), n, ce.shape[1], float(ce.shape[1]) ** 0.5)      # cc12m_1.py:294
         ff = torch.empty((n, 2 * self.mtw.numel()), dtype=torch.float32, device=dev)
         call("pmi_fourier_features", ptr(t), ptr(self.mtw), ptr(ff), n, self.mtw.numel())
+        if self.precise:
+            m = self.m
+            xin = torch.cat([cen, ff], dim=1)                                   # [N, 640] fp32 (layout only)
+            h = ops.linear_f32(xin, *m["a0"], act=ACT_RELU)
+            s = ops.linear_f32(xin, *m["askip"])
+            z1 = ops.linear_f32(h, *m["a2"], act=ACT_RELU, residual=s)
+            h = ops.linear_f32(z1, *m["b0"], act=ACT_RELU)
+            cond = ops.linear_f32(h, *m["b2"], residual=z1)
+            return ops.linear_f32(cond, self.mod_all, None)
         ce16, ff16 = torch.empty(cen.shape, dtype=tdt, device=dev), torch.empty(ff.shape, dtype=tdt, device=dev)
         call("pmi_cast_f32_to_16", ptr(cen), ptr(ce16), cen.numel(), ACT_NONE, dt)
         call("pmi_cast_f32_to_16", ptr(ff), ptr(ff16), ff.numel(), ACT_NONE, dt)
@@ -282,7 +300,7 @@ class VDiffEngine:
         if self.spec.get("t_input") == "log_snr":       # wikiart_256.py:288-292: features of log(alpha^2 / sigma^2), [N] scalars
             tf = torch.log(torch.cos(t * (torch.pi / 2)) ** 2 / torch.sin(t * (torch.pi / 2)) ** 2).contiguous()
         call("pmi_fourier_features", ptr(tf), ptr(self.tw), ptr(planes), n, 8)
-        x = torch.empty((n, hh, ww, 24), dtype=_hip.TORCH_DTYPE[dt], device=dev)
+        x = torch.empty((n, hh, ww, 48 if self.precise else 24), dtype=_hip.TORCH_DTYPE[dt], device=dev)
         call("pmi_prep_input", ptr(images), ptr(planes), 16, ptr(x), n, hh, ww, 24, dt)
         y = self._run(self.spec["net"], "net", x, mod)
         out = torch.empty((n, 3, hh, ww), dtype=torch.float32, device=dev)

@@ -35,7 +35,9 @@ def _rng(name: str, seed: int) -> np.random.Generator:
     return np.random.Generator(np.random.Philox(key=key))
 
 
-def synth_tensor(name: str, shape: Sequence[int], seed: int = 0, gain: float = 1.0) -> torch.Tensor:
+def synth_tensor(name: str, shape: Sequence[int], seed: int = 0, gain: float = 1.0, rounding: str = "bf16") -> torch.Tensor:
+    """rounding="bf16" (default): matrix-shaped parameters are bf16-representable; "none": full fp32 values (used with the
+    reference's own fp16 cast of the torso convolutions for the weight-packing fixtures)."""
     shape = tuple(int(s) for s in shape)
     g = _rng(name, seed)
     leaf = name.rsplit(".", 1)[-1]
@@ -52,26 +54,27 @@ def synth_tensor(name: str, shape: Sequence[int], seed: int = 0, gain: float = 1
         w = 1.0 + 0.1 * z
     else:  # biases and other vectors
         w = 0.05 * z
-    if len(shape) >= 2:
+    if len(shape) >= 2 and rounding == "bf16":
         w = _round_bf16(w)
     return torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32))
 
 
-def synth_state_dict(shapes: Mapping[str, Sequence[int]], seed: int = 0, workers: int = 8, gain: float = 1.0) -> Dict[str, torch.Tensor]:
+def synth_state_dict(shapes: Mapping[str, Sequence[int]], seed: int = 0, workers: int = 8, gain: float = 1.0,
+                     rounding: str = "bf16") -> Dict[str, torch.Tensor]:
     """Each tensor has its own name-keyed stream, so generation order / threading cannot change values."""
     from concurrent.futures import ThreadPoolExecutor
     keys = list(shapes)
     with ThreadPoolExecutor(max_workers=workers) as ex:
-        vals = list(ex.map(lambda k: synth_tensor(k, shapes[k], seed, gain), keys))
+        vals = list(ex.map(lambda k: synth_tensor(k, shapes[k], seed, gain, rounding), keys))
     return dict(zip(keys, vals))
 
 
-def synth_like(state_dict: Mapping[str, torch.Tensor], seed: int = 0, gain: float = 1.0) -> Dict[str, torch.Tensor]:
+def synth_like(state_dict: Mapping[str, torch.Tensor], seed: int = 0, gain: float = 1.0, rounding: str = "bf16") -> Dict[str, torch.Tensor]:
     """Synthetic replacement for every floating-point entry of ``state_dict``."""
     out = {}
     for k, v in state_dict.items():
         if torch.is_floating_point(v):
-            out[k] = synth_tensor(k, v.shape, seed, gain).to(v.dtype)
+            out[k] = synth_tensor(k, v.shape, seed, gain, rounding).to(v.dtype)
         else:
             out[k] = v.clone()
     return out

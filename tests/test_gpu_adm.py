@@ -2,10 +2,10 @@
 
 Tolerances (stated per north_star "within a stated fp32 tolerance"): weights are bf16-exact
 (perceptor_amd/utils/synth.py), so the only error source is rounding activations to the 16-bit
-MFMA input type through ~20-150 layers.  Measured-error based bounds, relative to max|eps|:
-  f16  (11-bit mantissa): 1.5e-2        bf16 (8-bit mantissa): 8e-2
-plus a relative-L2 bound (3e-3 / 2.5e-2) that is far tighter than any structural bug
-(wrong tap / wrong channel order / wrong norm group gives O(1) error).
+MFMA input type through ~20-150 layers.  Bounds of the single-pass 16-bit modes, relative to max|eps|, about 1.5-2x the
+measured values:   f16 (11-bit mantissa): 4e-3        bf16 (8-bit mantissa): 2.5e-2
+plus a relative-L2 bound (2.5e-3 / 2e-2).  The contract's absolute 1e-3 is met and asserted by the precise mode
+(tests/test_gpu_precise.py); these modes trade it for twice the MFMA throughput.
 """
 import pytest
 import torch
@@ -14,8 +14,8 @@ from conftest import golden
 
 pytestmark = pytest.mark.gpu
 
-TOL_MAX = {"f16": 1.5e-2, "bf16": 8e-2}
-TOL_L2 = {"f16": 3e-3, "bf16": 2.5e-2}
+TOL_MAX = {"f16": 4e-3, "bf16": 2.5e-2}     # x max|ref|; measured on MI355X: f16 1.0-2.7e-3, bf16 0.9-1.8e-2 (the < 1e-3 ABSOLUTE contract is
+TOL_L2 = {"f16": 2.5e-3, "bf16": 2e-2}      # asserted in precise mode: tests/test_gpu_precise.py)
 
 
 def _compare(got, ref, dtype, tag):

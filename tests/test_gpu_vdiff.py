@@ -8,8 +8,8 @@ from conftest import golden
 
 pytestmark = pytest.mark.gpu
 
-TOL_MAX = {"f16": 1.5e-2, "bf16": 8e-2}
-TOL_L2 = {"f16": 3e-3, "bf16": 2.5e-2}
+TOL_MAX = {"f16": 4e-3, "bf16": 2.5e-2}     # x max|ref|; measured on MI355X: f16 1.0-2.7e-3, bf16 0.9-1.8e-2 (the < 1e-3 ABSOLUTE contract is
+TOL_L2 = {"f16": 2.5e-3, "bf16": 2e-2}      # asserted in precise mode: tests/test_gpu_precise.py)
 
 
 def _compare(got, ref, dtype, tag):

@@ -54,6 +54,15 @@ def test_predictions_algebra():
     _close(sampling.v_step(img, vg, ft, tt), g["v_guided_step"], 1e-6)
 
 
+def test_adm_tiny_fp16_checkpoint_weights():
+    """fp32 weights with the torso convolutions cast to fp16 by the reference's own convert_to_fp16() (not bf16-representable)."""
+    from conftest import fp16_torso_state_dict
+    cfg = adm_unet.AdmConfig(64, 32, 1, (1, 2, 2), (2, 4), num_head_channels=16, use_scale_shift_norm=True, resblock_updown=True)
+    g = golden("adm_tiny_a_fp16w")
+    sd = fp16_torso_state_dict(adm_unet.state_dict_shapes(cfg), g)
+    _close(adm_unet.adm_unet_forward(sd, cfg, g["x"], g["t"]), g["y"], 1e-5)
+
+
 @pytest.mark.parametrize("tag,cfg", [
     ("a", adm_unet.AdmConfig(64, 32, 1, (1, 2, 2), (2, 4), num_head_channels=16, use_scale_shift_norm=True, resblock_updown=True)),
     ("b", adm_unet.AdmConfig(64, 32, 2, (1, 2), (2,), num_heads=2, use_new_attention_order=True)),
