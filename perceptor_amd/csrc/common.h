@@ -31,6 +31,9 @@ struct F16 {
   static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   }
+  static __device__ __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
 };
 struct BF16 {
   using elem = __bf16;
@@ -39,6 +42,9 @@ struct BF16 {
   static __device__ __forceinline__ u16 from_f(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
   static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(uint4 a, uint4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
 };
 

@@ -1,75 +1,84 @@
 // conv3x3 (stride 1, pad 1) for gfx950 MFMA, "weights-direct" form -- the dominant kernel of the UNets.
 //
-// Every wave owns a 256-pixel x 32-output-channel tile (8 image rows x 32 pixels; 8 MFMA 32x32x16 blocks = 128 accumulator
-// registers) and streams ITS OWN weights global -> VGPR, already in MFMA fragment order (packed once on the host, see
-// engine/ops.py::pack_frag): one coalesced 1 KB buffer load per fragment, no LDS and no cross-wave synchronisation on the
-// weight side.  Only the activation patch goes through LDS: per CK-channel input chunk the (TH+2) x 34 halo patch is
-// staged once (double-buffered) and serves all 9 taps of all waves of the workgroup -> ONE workgroup barrier per chunk
-// (9 x CK/16 x 8 = 288 (CK = 64) or 144 (CK = 32) MFMAs per wave between barriers; the round-1 kernel had one per tap).
+// A 512-thread workgroup owns 8 image rows x 32 pixels x 256 output channels; every wave owns a 256-pixel x 32-channel
+// tile (128 accumulator registers) and streams ITS OWN weights global -> VGPR, already in MFMA fragment order (packed once on the
+// host: engine/ops.py PackedLinear.frag / frag16): one coalesced 1 KB buffer load per fragment, no LDS and no cross-wave
+// synchronisation on the weight side.  Only the activation patch goes through LDS: per 64-channel input chunk the 10 x 34 halo
+// patch is staged once (double-buffered) and serves all 9 taps of all 8 waves -> ONE workgroup barrier per chunk (288
+// 32x32x16 MFMAs per wave between barriers; the round-1 kernel had one barrier per tap).
 //
-// Loop order inside a chunk is (dx, 16-channel k-step) with the three dy taps innermost: the 8 output rows of a wave need the
-// same 10 patch-row fragments for dy = 0, 1, 2, so a group of 24 MFMAs reads 10 fragments from LDS (0.42 ds_read_b128 per
-// MFMA; round 1: 0.75) and 3 weight fragments from global (prefetched two groups ahead in a 3-slot register ring).
-//   NWN: waves along output channels (BN = 32 NWN), NWM: waves along image rows (TH = 8 NWM)
-//   <8,1,CK=64>: 8x32 px x 256 ch, one workgroup per CU;  <4,1,CK=32>: 8x32 px x 128 ch, two workgroups per CU
-// LDS patch rows hold CK channels; the 16-byte chunk index is XOR-swizzled with the pixel index so that the 16 lanes of a
-// ds_read_b128 group (16 consecutive pixels, any tap shift) hit 16 different 16-byte slots.
+// Loop order inside a chunk is (dx, channel step) with the three dy taps innermost: the 8 output rows of a wave need the same 10
+// patch-row fragments for dy = 0, 1, 2, so a group reads 10 fragments from LDS for 24 (32x32x16) or 48 (16x16x32) MFMAs
+// (0.42 ds_read_b128 per 32-cycle MFMA slot; round 1: 0.75).  The fragments live in a rolling window of SIX registers (see below),
+// weights in a small register ring fed one or two groups ahead.
+//
+// MF16 selects v_mfma_f32_16x16x32 instead of 32x32x16: same FLOPs per cycle, but the chip holds a higher clock on it (this
+// kernel is power-limited: 1.4-1.65 GHz in the main loop).  The wave's tile is then 8 rows x 2 half-rows of 16 pixels x 2 blocks of
+// 16 channels, a k-step covers 32 channels, a group is (dx, 32-channel step, half-row) and the 6 weight fragments of a (dx, step)
+// pair serve both half-rows.
+//
+// LDS patch layout: one row per patch pixel, 64 channels + padding, NOT swizzled: a fragment read is (per-lane base) +
+// (compile-time offset).  Pitch 144 B (32x32x16: the 16 lanes of a ds_read_b128 group start at dwords 36 i) or 160 B (16x16x32: the
+// 16-byte slots 10 i + k-quarter): 16 different slots for 16 consecutive pixels at every tap shift -> conflict-free.
+//
 // Fused: nearest-x2 upsample of the input (patch gather), skip-concat (two sources), GroupNorm-apply(+FiLM)+activation on
 // the patch as it is written to LDS (zero padding stays zero); bias / per-sample bias / activation / residual (optionally
 // through a nearest-x2 upsample) / per-channel (sum, sumsq) of the output for the next GroupNorm in the epilogue, which
-// transposes the whole tile through LDS and writes full pixel rows (BN x 2 bytes contiguous).
+// transposes the whole tile through LDS and writes full pixel rows (512 contiguous bytes).
 #include "common.h"
 #include "../../include/perceptor_hip.h"
 
 #ifndef WD_ILV
-#define WD_ILV 4     // VALU instructions of the patch staging placed behind each MFMA (0: staging first, then the MFMAs)
+#define WD_ILV 4     // VALU instructions of the patch staging the scheduler is asked to place behind each output row's MFMAs
 #endif
 
 namespace {
 
 constexpr int PW = 34;
-
-// LDS patch layout: one row per patch pixel, CK channels + 16 bytes of padding, NOT swizzled: a fragment read is then
-// (per-lane base) + (compile-time offset), one address register for all 10 x 3 x CK/16 reads of a chunk (an XOR swizzle needs a
-// lane-dependent address per read; the compiler hoisted those ~120 addresses out of the chunk loop and spilled them).  With a row
-// pitch of 144 B (CK = 64) or 80 B (CK = 32) the 16 lanes of a ds_read_b128 group -- 16 consecutive pixels -- start at dwords
-// 36 i or 20 i (mod 64), i.e. on 16 different 4-dword slots: conflict-free for every tap shift.
-
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <typename T, int NWN, int NWM, int CK, int PRO>
-__global__ __launch_bounds__(NWN * NWM * 64, 2) void conv3x3_wd_kernel(const pmi_igemm_args a) {
-  constexpr int NW = NWN * NWM, NT = NW * 64;
-  constexpr int TH = 8 * NWM, PP = (TH + 2) * PW;
+template <typename T, int PRO, bool MF16>
+__global__ __launch_bounds__(512, 2) void conv3x3_wd_kernel(const pmi_igemm_args a) {
+  constexpr int NWN = 8, NW = 8, NT = 512, CK = 64;
+  constexpr int PP = 10 * PW;                          // patch pixels
   constexpr int CPR = CK / 8;                          // 16-byte chunks per patch pixel
-  constexpr int KS = CK / 16;                          // 16-channel k-steps per chunk
-  constexpr int NG = 3 * KS;                           // (dx, k-step) groups per chunk, 24 MFMAs each
-  constexpr int NPI = (PP * CPR + NT - 1) / NT;        // 16-byte staging pieces per thread per chunk
-  constexpr int ROW = CK * 2 + 16;                     // patch row pitch in bytes
+  constexpr int NG = 12;                               // groups per chunk: 3 dx x 4 steps of 16 channels, or 3 dx x 2 steps of 32 x 2 half-rows
+  constexpr int WGC = MF16 ? 6 : 12;                   // weight groups per chunk (3 dy fragments of 1 KB each, x 2 channel blocks with MF16)
+  constexpr int NWF = MF16 ? 6 : 3;                    // fragments per weight group
+  constexpr int GB = NWF * 1024;
+  constexpr int NPI = (PP * CPR + NT - 1) / NT;        // 16-byte staging pieces per thread per chunk (6)
+  constexpr int ROW = CK * 2 + (MF16 ? 32 : 16);       // patch row pitch in bytes
   constexpr int PATCH_BYTES = (NPI * NT / CPR) * ROW;  // padded to whole staging passes: no bounds test on the LDS writes
-  constexpr int BN = NWN * 32;
-  constexpr int NPX = 256 * NWM;
+  constexpr int BN = NWN * 32, NPX = 256;
   constexpr int SROW = BN * 2 + 16;                    // epilogue staging row: BN 16-bit channels + 16 B pad
   constexpr int EPI_BYTES = NPX * SROW + NW * BN * 8 + BN * 4;
-  constexpr int GB = 3 * 1024;                         // bytes of one group's weight fragments (3 dy x 64 lanes x 16 B)
-  static_assert(NPI <= NG, "one staging piece per group");
-  __shared__ __attribute__((aligned(16))) char smem[cmax(2 * PATCH_BYTES, EPI_BYTES)];
+  constexpr int MAXCIN = 2048;                         // fused-prologue coefficient table: a[Cin], b[Cin] fp32 of this image
+  constexpr int COEF_BYTES = PRO ? 2 * MAXCIN * 4 : 0;
+  constexpr int PPIX_BYTES = NPI * NT * 4;             // source pixel of every staged piece of this thread (kept out of the registers)
+  // Staging of the next patch: store slot k (k = 0..NPI-1) is group SG k; the piece it stores was loaded one slot earlier into
+  // the single carried register set (piece 0 in the previous chunk's last group).  With MF16 the store slots are the half-row-0
+  // groups, where only ONE weight set is live, so the prologue's temporaries fit the register file.
+  constexpr int SG = MF16 ? 2 : 1;
+  static_assert(SG * (NPI - 1) <= NG - 2, "the next patch must be complete before the barrier in the chunk's last group");
+  __shared__ __attribute__((aligned(16))) char smem[cmax(2 * PATCH_BYTES + COEF_BYTES + PPIX_BYTES, EPI_BYTES)];
+  float* const coef = (float*)(smem + 2 * PATCH_BYTES);
+  int* const ppix_s = (int*)(smem + 2 * PATCH_BYTES + COEF_BYTES);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int wm = wid / NWN, wn = wid % NWN;
+  const int wn = wid;
 
-  const int tiles_x = a.W / 32, tiles_y = a.H / TH, tiles_n = a.N / BN;
+  const int tiles_x = a.W / 32, tiles_y = a.H / 8, tiles_n = a.N / BN;
   const int nimg = a.M / (a.H * a.W);
   int logical = xcd_remap(blockIdx.x, nimg * tiles_y * tiles_x * tiles_n);
   const int tn = logical % tiles_n; logical /= tiles_n;
   const int tx = logical % tiles_x; logical /= tiles_x;
   const int ty = logical % tiles_y;
   const int img = logical / tiles_y;
-  const int y0 = ty * TH, x0 = tx * 32, n0 = tn * BN;
+  const int y0 = ty * 8, x0 = tx * 32, n0 = tn * BN;
 
-#ifdef PMI_STAMPS   // tools/conv_probe.py --stamps: phase timestamps (100 MHz) per workgroup
+#ifdef PMI_STAMPS   // tools/conv_probe.py --stamps: phase timestamps (100 MHz) per workgroup, shader clock per wave around the main loop
 #define STAMP(k) do { if (tid == 0 && a.ws) ((long long*)a.ws)[(int64_t)blockIdx.x * 8 + (k)] = (long long)wall_clock64(); } while (0)
 #define CSTAMP(k) do { if (lane == 0 && a.ws) { ((long long*)a.ws)[(1 << 19) + ((int64_t)blockIdx.x * 8 + wid) * 4 + (k)] = (long long)__builtin_amdgcn_s_memtime(); \
                                                 ((long long*)a.ws)[(1 << 19) + ((int64_t)blockIdx.x * 8 + wid) * 4 + (k) + 2] = (long long)wall_clock64(); } } while (0)
@@ -80,149 +89,187 @@ __global__ __launch_bounds__(NWN * NWM * 64, 2) void conv3x3_wd_kernel(const pmi
   STAMP(0);
   const int Cin = a.C0 + a.C1;
   const int nchunks = Cin / CK;
-  const int sc = tid % CPR;                            // 16-byte chunk (8 channels) of a patch pixel this thread stages (NT % CPR == 0)
+  const int sc = tid % CPR;                            // 16-byte chunk (8 channels) of a patch pixel this thread stages
   const int64_t img_px = (int64_t)a.Hin * a.Win;
   const u16* const A0i = (const u16*)a.A0 + (int64_t)img * img_px * a.lda0;
   const u16* const A1i = a.A1 ? (const u16*)a.A1 + (int64_t)img * img_px * a.lda1 : A0i;
   const int64_t bytes0 = ((img_px - 1) * a.lda0 + a.C0) * 2;
   const int64_t bytes1 = a.A1 ? ((img_px - 1) * a.lda1 + a.C1) * 2 : 0;
-  // this wave's weight stream: [chunk][dx][k-step][dy][lane][8] 16-bit, contiguous
-  const int64_t wslab = (int64_t)nchunks * NG * GB;
+  // this wave's weight stream: [chunk][dx][step][dy](x [16-channel block])[lane][8] 16-bit, contiguous in loop order
+  const int64_t wslab = (int64_t)nchunks * WGC * GB;
   const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc((const char*)a.Bf + (int64_t)(tn * NWN + wn) * wslab, wslab);
   const uint32_t wvo = (uint32_t)lane * 16u;
 
-  // ---- patch staging plan: source pixel (inside the image) per staged piece, -1 = zero padding ----
-  int ppix[NPI];
+  // ---- staging plan: source pixel (inside the image) per staged piece, -1 = zero padding; lives in LDS ([piece][thread]:
+  // conflict-free dword reads), as do the prologue's per-channel coefficients -- the main loop has no registers to spare ----
 #pragma unroll
   for (int i = 0; i < NPI; ++i) {
     const int pp = tid / CPR + (NT / CPR) * i;
     const int py = pp / PW, px = pp - py * PW;
     const int sy = y0 - 1 + py, sx = x0 - 1 + px;
     const bool inside = pp < PP && (unsigned)sy < (unsigned)a.H && (unsigned)sx < (unsigned)a.W;
-    ppix[i] = inside ? (sy >> a.up) * a.Win + (sx >> a.up) : -1;
+    ppix_s[i * NT + tid] = inside ? (sy >> a.up) * a.Win + (sx >> a.up) : -1;
+  }
+  if (PRO) {
+    for (int c = tid; c < Cin; c += NT) {
+      coef[c] = a.pro_a[(int64_t)img * Cin + c];
+      coef[MAXCIN + c] = a.pro_b[(int64_t)img * Cin + c];
+    }
+    __syncthreads();
   }
 
-  float ga[8], gb[8];
   // source of chunk `chunk`: which tensor, row pitch, channel offset (wave-uniform: C0 is a multiple of CK)
-  auto load_piece = [&](int chunk, int i, bool live) -> uint4 {          // !live: out-of-range offset, zeros, no traffic, no branch
+  auto load_piece = [&](int chunk, int pix, bool live) -> uint4 {        // !live: out-of-range offset, zeros, no traffic, no branch
     const int cbase = chunk * CK;
     const bool second = cbase >= a.C0;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(second ? A1i : A0i, second ? bytes1 : bytes0);
     const uint32_t ld2 = (uint32_t)(second ? a.lda1 : a.lda0) * 2u;
     const uint32_t so = (uint32_t)(cbase - (second ? a.C0 : 0)) * 2u;
-    const uint32_t vo = (ppix[i] >= 0 && live) ? (uint32_t)ppix[i] * ld2 + (uint32_t)sc * 16u : PMI_BUF_OOB;
+    const uint32_t vo = (pix >= 0 && live) ? (uint32_t)pix * ld2 + (uint32_t)sc * 16u : PMI_BUF_OOB;
     return buf_load16(rs, vo, so);
   };
-  auto load_coef = [&](int chunk) {
-    if (PRO) {
-      const float* pa = a.pro_a + (int64_t)img * Cin + chunk * CK + sc * 8;
-      const float* pb = a.pro_b + (int64_t)img * Cin + chunk * CK + sc * 8;
-      *(float4*)ga = *(const float4*)pa; *(float4*)(ga + 4) = *(const float4*)(pa + 4);
-      *(float4*)gb = *(const float4*)pb; *(float4*)(gb + 4) = *(const float4*)(pb + 4);
-    }
+  auto read_coef = [&](int chunk, float* ga, float* gb) {
+    const float* ca = coef + chunk * CK + sc * 8;
+    *(float4*)ga = *(const float4*)ca; *(float4*)(ga + 4) = *(const float4*)(ca + 4);
+    *(float4*)gb = *(const float4*)(ca + MAXCIN); *(float4*)(gb + 4) = *(const float4*)(ca + MAXCIN + 4);
   };
-  auto store_piece = [&](char* pbuf, int i, uint4 v) {
+  auto store_piece = [&](char* pbuf, int i, uint4 v, int pix, const float* ga, const float* gb) {
     if (PRO) {                                          // GroupNorm-apply + activation; zero padding stays zero
       float f[8];
       unpack8<T>(v, f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = act_apply(f[e] * ga[e] + gb[e], PRO - 1);
       v = pack8<T>(f);
-      const uint32_t keep = ppix[i] >= 0 ? 0xffffffffu : 0u;
+      const uint32_t keep = pix >= 0 ? 0xffffffffu : 0u;
       v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
     }
     *(uint4*)(pbuf + (tid / CPR) * ROW + sc * 16 + i * (NT / CPR) * ROW) = v;
   };
 
-  f32x16 acc[8];
+  f32x16 acc[MF16 ? 1 : 8];                             // 32x32x16: [row]
+  f32x4 acc4[MF16 ? 8 : 1][2][2];                       // 16x16x32: [row][half-row][16-channel block]
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < (MF16 ? 1 : 8); ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < (MF16 ? 8 : 1); ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc4[i][(r >> 3) & 1][(r >> 2) & 1][r & 3] = 0.f;
 
-  uint4 wq[3][3];                                       // [ring slot][dy]
+  uint4 wq[MF16 ? 2 : 3][NWF];                          // [ring slot][dy (x channel block)]
   auto load_wg = [&](int slot, int group) {             // groups past the end fall outside the resource: zeros (the range check
     const uint32_t vo = wvo + (uint32_t)group * (uint32_t)GB;   // covers the vector offset, so the group offset goes there)
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) wq[slot][dy] = buf_load16(rsrc_w, vo + dy * 1024u, 0);
+    for (int f = 0; f < NWF; ++f) wq[slot][f] = buf_load16(rsrc_w, vo + f * 1024u, 0);
   };
 
-  // ---- prologue: patch of chunk 0, weight groups 0 and 1 ----
+  // ---- prologue: patch of chunk 0, the first weight groups ----
   load_wg(0, 0);
-  load_wg(1, 1);
-  load_coef(0);
+  if (!MF16) load_wg(1, 1);
   {
-    uint4 pr[NPI];
+    uint4 p0[NPI];
+    float ga[8], gb[8];
+    if (PRO) read_coef(0, ga, gb);
 #pragma unroll
-    for (int i = 0; i < NPI; ++i) pr[i] = load_piece(0, i, true);
+    for (int i = 0; i < NPI; ++i) p0[i] = load_piece(0, ppix_s[i * NT + tid], true);
 #pragma unroll
-    for (int i = 0; i < NPI; ++i) store_piece(smem, i, pr[i]);
+    for (int i = 0; i < NPI; ++i) store_piece(smem, i, p0[i], ppix_s[i * NT + tid], ga, gb);
   }
   __syncthreads();
   STAMP(1);
   CSTAMP(0);
 
-  const int frag0 = (wm * 8 * PW + l31) * ROW + lhi * 16;   // byte offset of this lane's fragment piece for output row 0, tap dx = 0, k-step 0
-  // Rolling fragment registers: output row i of a group needs patch rows i, i+1, i+2, so fragment i is dead once row i's three
-  // MFMAs have issued and is reloaded right there with the NEXT group's fragment i -- the reads ride under the MFMAs of the
-  // current group (no read phase at the head of a group, no second register set).  The last group of a chunk prefetches from the
-  // other patch buffer, so the chunk's only barrier sits in front of that group's first prefetch: by then every wave has issued
-  // (and, through the barrier's lgkmcnt(0), received) its last read of the current buffer's successor-to-be-overwritten, and the
-  // next patch (staged in groups 1..NPG of this chunk) is complete.
-  constexpr int PPG = (NPI + NG - 3) / (NG - 2);       // staging pieces per group (loads in groups 0.., stores one group later)
-  constexpr int NPG = (NPI + PPG - 1) / PPG;           // groups that load pieces
-  static_assert(NPG <= NG - 2, "the next patch must be complete before the barrier in the chunk's last group");
-  uint4 xf[10];
+  // byte offset of this lane's fragment piece for output row 0, tap dx = 0, k-step 0 (half-row 0)
+  const int frag0 = MF16 ? (lane & 15) * ROW + (lane >> 4) * 16 : l31 * ROW + lhi * 16;
+  // byte offset of group g's fragments relative to frag0: 32x32x16: (dx, 16-channel step); 16x16x32: (dx, 32-channel step, half-row)
+  auto goff = [&](int g) -> int {
+    if (MF16) { const int q = g >> 1, s = g & 1; return (q / 2) * ROW + (q % 2) * 64 + s * 16 * ROW; }
+    return (g / 4) * ROW + (g % 4) * 32;
+  };
+  // Six fragment registers as a rolling window over the 10 patch rows of a group: row i's MFMAs need rows i, i+1, i+2; once they
+  // have issued, row i's register is reloaded -- with row i+6 of this group (i < 4), or with row i-4 of the NEXT group (i = 4, 5, 6;
+  // rows 3, 4, 5 of the next group replace rows 7, 8, 9 after the last output row).  Row r of group g therefore sits in register
+  // (r + 4 g) % 6; 4 NG is a multiple of 6, so the assignment repeats per chunk and every index is a compile-time constant.
+  // The last group of a chunk reads its own rows 6..9 from the current buffer (after output rows 0..3) and then prefetches the next
+  // chunk's rows from the other buffer: the chunk's only barrier sits between the two.
+  static_assert((4 * NG) % 6 == 0, "fragment window must repeat per chunk");
+  uint4 xf[6];
 #pragma unroll
-  for (int r = 0; r < 10; ++r) xf[r] = *(const uint4*)(smem + frag0 + r * PW * ROW);
+  for (int r = 0; r < 6; ++r) xf[r] = *(const uint4*)(smem + frag0 + r * PW * ROW);
+  // carried staging state: the piece waiting for its store slot, its source pixel, and the source pixel of the next load.
+  // Table reads (ppix_s, coef) are issued a phase before their use, so their waits are counted lgkmcnt(N), not drains.
+  int pixc = ppix_s[0 * NT + tid];
+  uint4 pr = load_piece(nchunks > 1 ? 1 : 0, pixc, nchunks > 1);      // piece 0 of the second chunk's patch
+  int pixn = ppix_s[1 * NT + tid];
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const char* const pb = smem + (chunk & 1) * PATCH_BYTES;
     char* const pn = smem + ((chunk + 1) & 1) * PATCH_BYTES;
-    const bool more = chunk + 1 < nchunks;              // last chunk: the staging below runs on zeros into the unused buffer (no branches
+    const bool more = chunk + 1 < nchunks;              // past the end the staging runs on zeros into the unused buffer (no branches
     const int cn = more ? chunk + 1 : chunk;            // around loads: the compiler then keeps exact vmcnt counts)
-    const int gbase = chunk * NG;
-    uint4 pr[PPG];
-#pragma unroll
-    for (int j = 0; j < PPG; ++j) pr[j] = make_uint4(0, 0, 0, 0);
+    const bool more2 = chunk + 2 < nchunks;
+    const int cn2 = more2 ? chunk + 2 : chunk;
+    const int gbase = chunk * WGC;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      load_wg((g + 2) % 3, gbase + g + 2);
-      if (g == 0) load_coef(cn);
-      uint4 prn[PPG];
-#pragma unroll
-      for (int j = 0; j < PPG; ++j) {
-        prn[j] = pr[j];
-        if (g < NPG && g * PPG + j < NPI) prn[j] = load_piece(cn, g * PPG + j, more);
-      }
-      if (g == NG - 1) __syncthreads();
+      if (MF16) { if ((g & 1) == 0) load_wg(((g >> 1) + 1) & 1, gbase + (g >> 1) + 1); }     // the next (dx, step) pair, one pair ahead
+      else load_wg((g + 2) % 3, gbase + g + 2);                                              // two groups ahead
+      const bool store_slot = g % SG == 0 && g / SG < NPI;            // stores piece g / SG from `pr`
+      const int lp = (g + 1 == NG) ? 0 : (g - (SG - 1)) / SG + 1;     // piece whose load is issued in this group (if load_slot)
+      const bool load_slot = (g + 1 == NG) || (g % SG == SG - 1 && lp < NPI);
+      float ga[8], gb[8];
+      if (PRO && store_slot) read_coef(cn, ga, gb);
+      uint4 prn = pr;
+      int pixl = pixc;
+      if (load_slot) { prn = load_piece(g + 1 == NG ? cn2 : cn, pixn, g + 1 == NG ? more2 : more); pixl = pixn; }
       __builtin_amdgcn_sched_barrier(0);   // keep the global loads in front of the MFMAs (the scheduler sinks them to their use)
-      // the GroupNorm-apply + activation of the pieces loaded one group ago (~100 VALU instructions each) is interleaved with this
-      // group's 24 MFMAs: an MFMA holds the vector issue port for 8 of its 32 cycles, the rest is free for VALU work
-      bool staging = false;
-      if (g >= 1 && g <= NPG) {
+      // GroupNorm-apply + activation of the piece loaded a slot ago, interleaved with this group's MFMAs by the hints below
+      if (store_slot) store_piece(pn, g / SG, pr, pixc, ga, gb);
+      const char* const cb0 = pb + frag0 + goff(g);                                // this group's fragments
+      const char* const nb = (g + 1 < NG ? pb : pn) + frag0 + goff((g + 1) % NG);  // next group's (next chunk: the other buffer)
+      auto rows = [&](int i0, int i1) {
 #pragma unroll
-        for (int j = 0; j < PPG; ++j)
-          if ((g - 1) * PPG + j < NPI) { store_piece(pn, (g - 1) * PPG + j, pr[j]); staging = true; }
+        for (int i = i0; i < i1; ++i) {
+          if constexpr (MF16) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+              for (int cb = 0; cb < 2; ++cb)
+                acc4[i][g & 1][cb] = T::mfma16(wq[(g >> 1) & 1][dy * 2 + cb], xf[(i + dy + 4 * g) % 6], acc4[i][g & 1][cb]);
+          } else {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) acc[i] = T::mfma32(wq[g % 3][dy], xf[(i + dy + 4 * g) % 6], acc[i]);
+          }
+          if (i < 4) xf[(i + 4 * g) % 6] = *(const uint4*)(cb0 + (i + 6) * PW * ROW);
+          else if (i < 7) xf[(i + 4 * g) % 6] = *(const uint4*)(nb + (i - 4) * PW * ROW);
+          else {
+#pragma unroll
+            for (int r = 3; r < 6; ++r) xf[(r + 4 + 4 * g) % 6] = *(const uint4*)(nb + r * PW * ROW);
+          }
+        }
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, MF16 ? 6 : 3, 0);   // the MFMAs of output row i
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);              // reload the freed fragment register
+          if (PRO && store_slot && i >= 2) __builtin_amdgcn_sched_group_barrier(0x002, WD_ILV * 4, 0);   // staging VALU, once the coefficients are in
+        }
+      };
+      if (g == NG - 1) {
+        // the chunk's barrier: rows 0..3 of this group issue the wave's LAST reads of the current patch buffer (which the next
+        // chunk's staging overwrites); rows 4..7 prefetch from the other buffer, whose staging (slots 0..NPI-1) every wave has finished
+        rows(0, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        rows(4, 8);
+      } else {
+        rows(0, 8);
       }
-      // next group's fragments: (dx, k-step) of group g+1 in this chunk, or group 0 of the next chunk from the other buffer
-      const char* const nb = (g + 1 < NG ? pb : pn) + frag0 + (((g + 1) % NG) / KS) * ROW + (((g + 1) % NG) % KS) * 32;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) acc[i] = T::mfma32(wq[g % 3][dy], xf[i + dy], acc[i]);
-        xf[i] = *(const uint4*)(nb + i * PW * ROW);
-      }
-      xf[8] = *(const uint4*)(nb + 8 * PW * ROW);
-      xf[9] = *(const uint4*)(nb + 9 * PW * ROW);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);        // 3 MFMAs of output row i
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // reload fragment i
-        if (PRO && staging) __builtin_amdgcn_sched_group_barrier(0x002, WD_ILV * 3 * PPG, 0);   // staging VALU
-      }
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-      for (int j = 0; j < PPG; ++j) pr[j] = prn[j];
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                // rows 8, 9 were freed by the last output row as well
+      // source pixel of the piece the NEXT load slot fetches (read now, used a group or two later)
+      int pixn2 = pixn;
+      if (load_slot) pixn2 = ppix_s[(((g + 1 == NG ? 0 : lp) + 1) % NPI) * NT + tid];
+      pr = prn; pixc = pixl; pixn = pixn2;
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -240,16 +287,13 @@ __global__ __launch_bounds__(NWN * NWM * 64, 2) void conv3x3_wd_kernel(const pmi
     if (a.nbias) b += a.nbias[(int64_t)img * (a.ldnb ? a.ldnb : a.N) + n];
     bsm[c] = b;
   }
-  constexpr int LPP = BN / 8;                          // lanes per pixel row at write-out (16 B = 8 channels each)
-  constexpr int PPI = 64 / LPP;                        // pixels per store instruction
-  constexpr int PXW = NPX / NW;                        // pixels written out per wave
-  constexpr int NWI = PXW / PPI;                       // store instructions per wave
-  const int q = lane % LPP, psub = lane / LPP;
+  constexpr int NWI = 16;                              // store instructions per wave: 2 pixel rows (512 B each) per instruction
+  const int q = lane & 31, psub = lane >> 5;
   const int cl0 = q * 8;
   uint4 rres[NWI];
 #pragma unroll
   for (int t = 0; t < NWI; ++t) {                      // residual loads fly while the accumulators are staged
-    const int p = wid * PXW + t * PPI + psub;
+    const int p = wid * 32 + t * 2 + psub;
     const int y = y0 + (p >> 5), x = x0 + (p & 31);
     rres[t] = make_uint4(0, 0, 0, 0);
     if (a.R) {
@@ -259,20 +303,39 @@ __global__ __launch_bounds__(NWN * NWM * 64, 2) void conv3x3_wd_kernel(const pmi
     }
   }
   __syncthreads();                                     // bsm visible (the main loop's last barrier already freed the patch buffers)
+  if constexpr (MF16) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int cl = wn * 32 + 8 * g + 4 * lhi;
-      const float4 b = *(const float4*)(bsm + cl);
-      float v[4] = {acc[i][4 * g] * a.alpha + b.x, acc[i][4 * g + 1] * a.alpha + b.y,
-                    acc[i][4 * g + 2] * a.alpha + b.z, acc[i][4 * g + 3] * a.alpha + b.w};
-      if (a.act != PMI_ACT_NONE) {
+      for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
+        for (int cb = 0; cb < 2; ++cb) {
+          const int cl = wn * 32 + cb * 16 + 4 * (lane >> 4);
+          const float4 b = *(const float4*)(bsm + cl);
+          const f32x4 c = acc4[i][sx][cb];
+          float v[4] = {c[0] * a.alpha + b.x, c[1] * a.alpha + b.y, c[2] * a.alpha + b.z, c[3] * a.alpha + b.w};
+          if (a.act != PMI_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
+          }
+          *(uint2*)(stg + (i * 32 + sx * 16 + (lane & 15)) * SROW + cl * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
+        }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cl = wn * 32 + 8 * g + 4 * lhi;
+        const float4 b = *(const float4*)(bsm + cl);
+        float v[4] = {acc[i][4 * g] * a.alpha + b.x, acc[i][4 * g + 1] * a.alpha + b.y,
+                      acc[i][4 * g + 2] * a.alpha + b.z, acc[i][4 * g + 3] * a.alpha + b.w};
+        if (a.act != PMI_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
+        }
+        *(uint2*)(stg + (i * 32 + l31) * SROW + cl * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
       }
-      *(uint2*)(stg + ((wm * 8 + i) * 32 + l31) * SROW + cl * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
-    }
+  }
   __syncthreads();
   STAMP(6);
   float cs[16];                                        // [0..7] sums, [8..15] sums of squares of this lane's 8 channels
@@ -280,7 +343,7 @@ __global__ __launch_bounds__(NWN * NWM * 64, 2) void conv3x3_wd_kernel(const pmi
   for (int e = 0; e < 16; ++e) cs[e] = 0.f;
 #pragma unroll
   for (int t = 0; t < NWI; ++t) {
-    const int p = wid * PXW + t * PPI + psub;
+    const int p = wid * 32 + t * 2 + psub;
     uint4 v = *(const uint4*)(stg + p * SROW + cl0 * 2);
     if (a.R || a.stats) {
       float f[8];
@@ -301,11 +364,8 @@ __global__ __launch_bounds__(NWN * NWM * 64, 2) void conv3x3_wd_kernel(const pmi
   STAMP(7);
   if (a.stats) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      if (LPP <= 16) cs[e] += __shfl_xor(cs[e], 16);
-      cs[e] += __shfl_xor(cs[e], 32);
-    }
-    if (lane < LPP) {
+    for (int e = 0; e < 16; ++e) cs[e] += __shfl_xor(cs[e], 32);
+    if (lane < 32) {
       float* const slot = stat + (wid * BN + cl0) * 2;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { slot[2 * e] = cs[e]; slot[2 * e + 1] = cs[8 + e]; }
@@ -334,13 +394,9 @@ __global__ __launch_bounds__(NWN * NWM * 64, 2) void conv3x3_wd_kernel(const pmi
 template <typename T, int PRO>
 int launch_p(const pmi_igemm_args& a, hipStream_t s, int cfg) {
   const int nimg = a.M / (a.H * a.W);
-  if (cfg == 4) {          // 8x32 px x 256 ch, 8 waves, one workgroup per CU
-    const int tiles = nimg * (a.H / 8) * (a.W / 32) * (a.N / 256);
-    hipLaunchKernelGGL((conv3x3_wd_kernel<T, 8, 1, 64, PRO>), dim3(tiles), dim3(512), 0, s, a);
-  } else {                 // 8x32 px x 128 ch, 4 waves, two workgroups per CU
-    const int tiles = nimg * (a.H / 8) * (a.W / 32) * (a.N / 128);
-    hipLaunchKernelGGL((conv3x3_wd_kernel<T, 4, 1, 32, PRO>), dim3(tiles), dim3(256), 0, s, a);
-  }
+  const int tiles = nimg * (a.H / 8) * (a.W / 32) * (a.N / 256);
+  if (cfg == 6) hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, true>), dim3(tiles), dim3(512), 0, s, a);    // v_mfma_f32_16x16x32
+  else hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, false>), dim3(tiles), dim3(512), 0, s, a);             // config 4: 32x32x16
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }

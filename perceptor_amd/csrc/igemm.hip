@@ -545,6 +545,7 @@ extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a);
 int pmi_conv3x3_halo_launch(const pmi_igemm_args* a, int cfg, void* stream);
 int pmi_conv3x3_wd_launch(const pmi_igemm_args* a, int cfg, void* stream);   // conv_wd.hip: tile configs 4, 5
 void pmi_conv3x3_allow_wd(int v);
+void pmi_conv3x3_wd_mf16(int v);
 int pmi_gemm_lt(const pmi_igemm_args* a, void* stream);          // gemm_lt.hip: 0 = done by hipBLASLt, 1 = use the generic kernel
 int pmi_gemm_lt_eligible(const pmi_igemm_args* a);
 void pmi_gemm_lt_enable(int v);
@@ -585,6 +586,7 @@ extern "C" int pmi_set_option(int key, int value) {
   if (key == 4) { pmi_gemm_lt_enable(value); return 0; }
   if (key == 5) { pmi_gemm_lt_margin(value); return 0; }
   if (key == 6) { pmi_conv3x3_allow_wd(value); return 0; }
+  if (key == 7) { pmi_conv3x3_wd_mf16(value); return 0; }
   return PMI_ERR_ARG;
 }
 

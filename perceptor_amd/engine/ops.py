@@ -112,6 +112,16 @@ class PackedLinear:
     def K(self):
         return self.taps * self.cin_p
 
+    def frag16(self, ck: int) -> torch.Tensor:
+        """Fragment order for the 16x16x32 MFMA form of the weights-direct kernel:
+        [N/32][Cin/ck][dx][ck/32][dy][16-channel block][lane = 16*(k quarter) + channel][8 k]."""
+        key = ("mf16", ck)
+        if key not in self._frag:
+            assert self.taps == 9 and self.n_p % 32 == 0 and self.cin_p % ck == 0
+            w = self.w.view(self.n_p // 32, 2, 16, 3, 3, self.cin_p // ck, ck // 32, 4, 8)   # nb, cb, r16, dy, dx, chunk, k32, q4, j
+            self._frag[key] = w.permute(0, 5, 4, 6, 3, 1, 7, 2, 8).contiguous()
+        return self._frag[key]
+
     def frag(self, ck: int) -> torch.Tensor:
         """The 3x3 weights in MFMA fragment order for the weights-direct kernel (csrc/conv_wd.hip):
         [N/32][Cin/ck][dx][ck/16][dy][lane = 32*(k half) + channel][8 k] -- every (n-block, chunk, dx, k-step, dy)
@@ -174,7 +184,7 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
     if conv and lin.taps == 9 and stride == 1 and HALO_ENABLED and WD_ENABLED and lin.n_p % 128 == 0 and lin.cin_p % 64 == 0:
         a.Bf = 1                       # ask which tile config the weights-direct kernel would run, then hand it that packing
         cfg = _hip.lib().pmi_conv3x3_halo_config(C.byref(a))
-        a.Bf = ptr(lin.frag(64 if cfg == 4 else 32)) if cfg in (4, 5) else None
+        a.Bf = ptr(lin.frag16(64)) if cfg == 6 else ptr(lin.frag(64)) if cfg == 4 else None
     if prologue is not None:
         ca, cb, pact = prologue
         if HALO_ENABLED and not lin.split and _hip.lib().pmi_conv3x3_halo_config(C.byref(a)) >= 0:

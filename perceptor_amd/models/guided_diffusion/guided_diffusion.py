@@ -19,6 +19,7 @@ import torch
 from ...engine import adm
 from ...utils.synth import synth_state_dict
 from ...utils.image_space import images_from_x
+from ...utils.param_tree import ParamTree
 from .predictions import Predictions
 
 
@@ -29,32 +30,7 @@ def linear_alphas_cumprod(n: int = 1000) -> np.ndarray:
     return np.cumprod(1.0 - betas, axis=0)
 
 
-class WeightStore(torch.nn.Module):
-    """Holds the reference-named fp32 master weights (state-dict compatibility)."""
-
-    def __init__(self, sd: Dict[str, torch.Tensor]):
-        super().__init__()
-        self._sd = {k: v.detach() for k, v in sd.items()}
-
-    def state_dict(self, *a, prefix="", **k):
-        return {prefix + n: v for n, v in self._sd.items()}
-
-    def load_state_dict(self, sd, strict=True):
-        missing = [k for k in self._sd if k not in sd]
-        unexpected = [k for k in sd if k not in self._sd]
-        if strict and (missing or unexpected):
-            raise RuntimeError(f"state dict mismatch: missing {missing[:5]}, unexpected {unexpected[:5]}")
-        for k in self._sd:
-            if k in sd:
-                if tuple(sd[k].shape) != tuple(self._sd[k].shape):
-                    raise RuntimeError(f"size mismatch for {k}: {tuple(sd[k].shape)} vs {tuple(self._sd[k].shape)}")
-                self._sd[k] = sd[k].detach().float()
-
-    def parameters(self, recurse=True):
-        return iter(self._sd.values())
-
-    def named_parameters(self, prefix="", recurse=True, remove_duplicate=True):
-        return iter((prefix + ("." if prefix else "") + k, v) for k, v in self._sd.items())
+WeightStore = ParamTree      # frozen reference-named parameters as a module tree (utils/param_tree.py)
 
 
 _CONFIGS = {"standard": (adm.openimages_config, (3, 512, 512)), "pixelart": (adm.pixelart_config, (3, 256, 256))}
@@ -90,19 +66,25 @@ class GuidedDiffusion(torch.nn.Module):
         ac = linear_alphas_cumprod(1000)
         self.schedule_alphas = torch.nn.Parameter(torch.from_numpy(ac).sqrt().float(), requires_grad=False)
         self.schedule_sigmas = torch.nn.Parameter((1 - torch.from_numpy(ac)).sqrt().float(), requires_grad=False)
-        self.engine: Optional[adm.AdmEngine] = None
+        self._engine: Optional[adm.AdmEngine] = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_engine", None))
 
-    def to(self, device):
-        device = torch.device(device)
-        super().to(device)
-        if device.type == "cuda":
-            self.engine = adm.AdmEngine(self.config, self.model.state_dict(), device, self.compute_dtype)
-        else:
-            self.engine = None
+    @property
+    def engine(self) -> Optional[adm.AdmEngine]:
+        """The HIP engine holds packed 16-bit copies of the weights: built on first use on a HIP device, dropped (and rebuilt from the
+        current parameters) whenever the module moves or a state dict is loaded."""
+        if self._engine is None and self.device.type == "cuda":
+            self._engine = adm.AdmEngine(self.config, self.model.state_dict(), self.device, self.compute_dtype)
+        return self._engine
+
+    def _apply(self, fn, *a, **k):          # .to() / .cuda() / .cpu() / .float() ... all come through here
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def to(self, *args, **kwargs):
+        super().to(*args, **kwargs)
+        self.engine                           # noqa: B018  build the engine now (as before): packing 558 M weights takes seconds
         return self
-
-    def cuda(self, device=None):
-        return self.to(torch.device("cuda", device if device is not None else torch.cuda.current_device()))
 
     @property
     def device(self):

@@ -17,6 +17,7 @@ import torch
 from .. import _hip
 from .._hip import call, ptr
 from ..engine import vit
+from ..utils.param_tree import ParamTree
 from ..utils.synth import synth_state_dict
 
 # (architecture, weights) pairs the reference accepts (docstring of models/open_clip.py:24-44)
@@ -84,6 +85,11 @@ class OpenCLIP(torch.nn.Module):
             raise RuntimeError(f"pretrained weights {architecture}/{weights} cannot be downloaded (no network): "
                                "pass checkpoint=<visual state dict> or weights='synthetic'")
         self.quick_gelu = quick_gelu if quick_gelu is not None else ("-quickgelu" in architecture or weights == "openai")
+        if precision == "fp32":
+            # the reference default (losses/clip/clip.py:11); this path has no fp32 tower: say so instead of silently lowering it
+            import warnings
+            warnings.warn("precision='fp32' requested: the HIP CLIP tower multiplies in bf16 on the MFMA (fp32 accumulation, fp32 residual "
+                          "stream, LayerNorm and softmax); embedding rel-L2 error vs fp32 ~4e-3 (tests/test_gpu_clip.py)", RuntimeWarning, stacklevel=2)
         self.precision = {None: "bf16", "fp16": "f16", "f16": "f16", "bf16": "bf16", "fp32": "bf16"}[precision]
         shapes = vit.vit_state_dict_shapes(self.cfg)
         if checkpoint is not None:
@@ -94,23 +100,33 @@ class OpenCLIP(torch.nn.Module):
                 raise RuntimeError("checkpoint does not contain the visual tower's tensors")
         else:
             sd = synth_state_dict(shapes, seed)
-        self._sd = sd
-        self.anchor = torch.nn.Parameter(torch.zeros(1), requires_grad=False)
-        self.engine: Optional[vit.VitEngine] = None
+        # the reference holds the open_clip model as self.model with the image tower under "visual." (models/open_clip.py:65-76)
+        self.model = ParamTree({"visual." + k: v for k, v in sd.items()})
+        self._engine: Optional[vit.VitEngine] = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_engine", None))
         self.output_dim = self.cfg[5]
 
-    def to(self, device):
-        device = torch.device(device)
-        super().to(device)
-        self.engine = vit.VitEngine(self.cfg, self._sd, device, self.precision, self.quick_gelu) if device.type == "cuda" else None
-        return self
+    def visual_state_dict(self):
+        return {k[len("visual."):]: v for k, v in self.model.state_dict().items()}
 
-    def cuda(self, device=None):
-        return self.to(torch.device("cuda", device if device is not None else torch.cuda.current_device()))
+    @property
+    def engine(self) -> Optional[vit.VitEngine]:
+        if self._engine is None and self.device.type == "cuda":
+            self._engine = vit.VitEngine(self.cfg, self.visual_state_dict(), self.device, self.precision, self.quick_gelu)
+        return self._engine
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def to(self, *args, **kwargs):
+        super().to(*args, **kwargs)
+        self.engine                           # noqa: B018
+        return self
 
     @property
     def device(self):
-        return self.anchor.device
+        return next(self.model.parameters()).device
 
     @property
     def image_size(self):

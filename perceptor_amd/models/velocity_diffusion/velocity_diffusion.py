@@ -48,21 +48,30 @@ class VelocityDiffusion(torch.nn.Module):
         self.model = WeightStore(sd)
         if self.spec["cond"]:
             self.model.clip_model = "ViT-B-16"      # cc12m_1.py:116
-        self.anchor = torch.nn.Parameter(torch.zeros(1), requires_grad=False)
-        self.engine: Optional[vdiff.VDiffEngine] = None
+        self._engine: Optional[vdiff.VDiffEngine] = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_engine", None))
 
-    def to(self, device):
-        device = torch.device(device)
-        super().to(device)
-        self.engine = vdiff.VDiffEngine(self.spec, self.model.state_dict(), device, self.compute_dtype) if device.type == "cuda" else None
+    @property
+    def engine(self) -> Optional[vdiff.VDiffEngine]:
+        """Built on first use on a HIP device; dropped when the module moves or a state dict is loaded (see GuidedDiffusion.engine)."""
+        if self._engine is None and self.device.type == "cuda":
+            self._engine = vdiff.VDiffEngine(self.spec, self.model.state_dict(), self.device, self.compute_dtype)
+        return self._engine
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def to(self, *args, **kwargs):
+        # the reference halves the net on cuda (velocity_diffusion.py:34-38); here the fp32 masters stay fp32 and the engine packs
+        # its own 16-bit (or precise) copies
+        super().to(*args, **kwargs)
+        self.engine                           # noqa: B018
         return self
-
-    def cuda(self, device=None):
-        return self.to(torch.device("cuda", device if device is not None else torch.cuda.current_device()))
 
     @property
     def device(self):
-        return self.anchor.device
+        return next(self.model.parameters()).device
 
     @property
     def shape(self):

@@ -103,3 +103,52 @@ def test_wrapper_errors_and_records():
     assert p.replace(predicted_noise=z + 1).predicted_noise.sum() == 48
     d = models.OpenCLIP.spherical_distance(torch.eye(3)[:1], torch.eye(3)[1:2])
     assert torch.allclose(d, torch.tensor([[torch.pi**2 / 8]]))
+
+
+# ---- state-dict compatibility of the wrappers (.to() / .parameters() / .state_dict() must cover the network) ----
+_TINY_ADM = dict(image_size=64, model_channels=32, num_res_blocks=1, channel_mult=(1, 2), attention_ds=(2,), num_head_channels=16,
+                 use_scale_shift_norm=True, resblock_updown=True)
+
+
+def test_guided_diffusion_state_dict_covers_the_unet_and_round_trips(tmp_path):
+    import torch
+    from perceptor_amd import models
+    from perceptor_amd.engine import adm
+    cfg = adm.AdmConfig(**_TINY_ADM)
+    m = models.GuidedDiffusion("standard", config=cfg)
+    shapes = adm.state_dict_shapes(cfg)
+    sd = m.state_dict()
+    assert set(sd) == {"model." + k for k in shapes} | {"schedule_alphas", "schedule_sigmas"}      # the reference wrapper's keys
+    assert all(tuple(sd["model." + k].shape) == tuple(s) for k, s in shapes.items())
+    assert sum(p.numel() for p in m.parameters()) == sum(v.numel() for v in sd.values())
+    assert not any(p.requires_grad for p in m.parameters())                                          # frozen, as guided_diffusion.py:41
+    # torch.save / load into a model with other weights reproduces every tensor
+    path = tmp_path / "wrapper.pt"
+    torch.save(sd, path)
+    m2 = models.GuidedDiffusion("standard", config=cfg, seed=1)
+    assert not torch.equal(m2.state_dict()["model.out.2.weight"], sd["model.out.2.weight"])
+    m2.load_state_dict(torch.load(path, weights_only=True))
+    assert all(torch.equal(v, m2.state_dict()[k]) for k, v in sd.items())
+    # a reference checkpoint (UNet keys, fp16 torso convolutions as unet.py:610-616 leaves them) through checkpoint=
+    ref_ckpt = {k[len("model."):]: (v.half() if v.ndim >= 3 and not k.startswith("model.out.") else v) for k, v in sd.items() if k.startswith("model.")}
+    torch.save(ref_ckpt, tmp_path / "unet.pt")
+    m3 = models.GuidedDiffusion("standard", config=cfg, checkpoint=str(tmp_path / "unet.pt"))
+    got = m3.model.state_dict()
+    assert all(torch.equal(got[k], v.float()) for k, v in ref_ckpt.items())
+    with __import__("pytest").raises(RuntimeError):
+        m3.load_state_dict({"model.bogus": torch.zeros(1)})
+
+
+def test_velocity_diffusion_and_clip_state_dicts():
+    import torch
+    from perceptor_amd import models
+    from perceptor_amd.engine import vdiff, vit
+    spec = vdiff.make_spec("tiny", (3, 32, 32), [64, 128, 128], 2, 2, 4, 1, True)
+    m = models.VelocityDiffusion("tiny", spec=spec)
+    assert set(m.state_dict()) == {"model." + k for k in vdiff.state_dict_shapes(spec)}
+    m2 = models.VelocityDiffusion("tiny", spec=spec, seed=3)
+    m2.load_state_dict(m.state_dict())
+    assert all(torch.equal(a, b) for a, b in zip(m.parameters(), m2.parameters()))
+    c = models.OpenCLIP("tiny-test", "synthetic", config=(32, 8, 64, 2, 1, 32))
+    assert set(c.state_dict()) == {"model.visual." + k for k in vit.vit_state_dict_shapes((32, 8, 64, 2, 1, 32))}
+    assert c.device.type == "cpu" and c.engine is None

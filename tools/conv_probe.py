@@ -22,7 +22,7 @@ w = torch.randn(a.cout, a.cin, 3, 3, generator=g) / (a.cin * 9) ** 0.5
 lin = ops.PackedLinear(w, torch.zeros(a.cout), dt, dev)
 pro = None
 if a.pro:
-    pro = (torch.ones(a.n, a.cin, device=dev), torch.zeros(a.n, a.cin, device=dev), 2)
+    pro = (torch.ones(a.n, a.cin, device=dev), torch.zeros(a.n, a.cin, device=dev), {1: 2, 2: 0, 3: 1}[a.pro])   # --pro 1: SiLU, 2: affine only, 3: ReLU
 flops = 2.0 * a.n * a.hw * a.hw * a.cin * a.cout * 9
 from perceptor_amd import _hip
 _hip.lib().pmi_set_option(1, a.cfg)
