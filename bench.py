@@ -56,7 +56,6 @@ def parse():
                    help="UNet arithmetic: bf16 / f16 single-pass MFMA, or precise (hi + lo f16 pairs, eps max-abs error < 1e-3 vs the fp32 reference)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-events", action="store_true")
-    p.add_argument("--lt-margin", type=int, default=None, help="percent a hipBLASLt candidate must beat the heuristic pick by to replace it (A/B)")
     p.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (helps launch-bound small configs such as c1)")
     p.add_argument("--dump-kernels", default=None, help="write per-launch (ms, GFLOP, MB) of the timed conv3x3 launches of the last step to this file")
     p.add_argument("--rehearse", action="store_true", help="launcher / collective rehearsal without the model: every rank joins the process group "
@@ -195,9 +194,6 @@ def main():
     from perceptor_amd.engine import ops
     from perceptor_amd.utils.synth import seeded_noise
 
-    if a.lt_margin is not None:
-        from perceptor_amd import _hip
-        _hip.lib().pmi_set_option(5, a.lt_margin)
     model_name, res, nb, clip_arch = CONFIGS[a.config]
     is_v = model_name not in ("standard", "pixelart")
     model = (models.VelocityDiffusion(model_name, dtype=a.dtype) if is_v else models.GuidedDiffusion(model_name, dtype=a.dtype)).to(dev)

@@ -78,6 +78,9 @@ int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream);
  * workgroups per CU, 3: 8x32 px x <= 32 output channels; csrc/conv_wd.hip (weights-direct, needs Bf != NULL): 4: 8x32 px x 256 ch, 5: 8x32 px x 128 ch;
  * -1 when pmi_igemm uses the generic implicit-GEMM kernel (which has no fused prologue). */
 int pmi_conv3x3_halo_config(const pmi_igemm_args* a);
+/* 1 when the weights-direct GEMM (csrc/gemm_wd.hip) takes this call: plain GEMM (taps 1, one source, no per-sample bias / statistics / prologue),
+ * K % 128 == 0, N % 256 == 0 and Bf = the weights in its fragment order [N/32][K/128][4][2][64 lanes][8] */
+int pmi_gemm_wd_eligible(const pmi_igemm_args* a);
 /* split-K factor recommended for this shape (1 = none); with splitk = S the caller passes ws = S*M*N floats */
 int pmi_igemm_splitk(const pmi_igemm_args* a);
 /* number of per-image partial rows the fused output statistics of this call would produce (0: not available for this shape) */
@@ -85,8 +88,8 @@ int pmi_igemm_stats_rows(const pmi_igemm_args* a);
 /* debugging / A-B switches: key 0 = allow the LDS-halo conv3x3 kernel (default 1, returns the previous value);
  * key 1 = force halo tile config 0/1/2 where eligible (-1 = automatic);
  * key 2 = prefer the 8-wave 256-channel halo config over two 4-wave workgroups per CU where the grid allows (default 1);
- * key 4 = route plain GEMMs (one source, no convolution gather, no fused activation / statistics) to hipBLASLt (default 1);
- * key 5 = percent by which a hipBLASLt candidate must beat the heuristic's first pick to replace it when a shape is first timed (default 8). */
+ * key 6 = allow the weights-direct conv3x3 kernel (default 1); key 7 = its 16x16x32-MFMA form, tile config 6, instead of config 4 (default 1).
+ * The library links no vendor GEMM / BLAS: every kernel it launches is in csrc/. */
 int pmi_set_option(int key, int value);
 
 /* ---- "precise" mode helpers (dtype 2: hi + lo f16 pairs, eps max-abs error < 1e-3 vs the fp32 reference path) ----------------

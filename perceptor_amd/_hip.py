@@ -63,6 +63,7 @@ _PROTOS = {
     "pmi_igemm_stats_rows": ([C.POINTER(IgemmArgs)],),
     "pmi_igemm_splitk": ([C.POINTER(IgemmArgs)],),
     "pmi_set_option": ([_I, _I],),
+    "pmi_gemm_wd_eligible": ([C.POINTER(IgemmArgs)],),
     "pmi_gemm_f32": ([C.POINTER(GemmF32Args), _P],),
     "pmi_softmax_f32": ([_P, _I, _I, _I, _F, _P],),
     "pmi_split_from_f32": ([_P, _I, _P, _L, _I, _P],),

@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libperceptor_hip.so")
-SOURCES = ["igemm.hip", "conv3x3.hip", "conv_wd.hip", "norm.hip", "attn.hip", "elementwise.hip", "clip.hip", "f32gemm.hip", "gemm_lt.hip"]
+SOURCES = ["igemm.hip", "conv3x3.hip", "conv_wd.hip", "gemm_wd.hip", "norm.hip", "attn.hip", "elementwise.hip", "clip.hip", "f32gemm.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 
 
@@ -42,7 +42,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
     with ThreadPoolExecutor(max_workers=min(7, len(srcs))) as ex:
         objs = list(ex.map(compile_one, srcs))
     if force or _stale(lib, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, "-L/opt/rocm/lib", "-lhipblaslt"]   # hipBLASLt: plain library GEMMs only
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

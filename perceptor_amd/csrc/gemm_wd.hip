@@ -1,0 +1,266 @@
+// Plain GEMM for gfx950 MFMA in the "weights-direct" form of conv_wd.hip -- the ViT linears of the CLIP tower, their
+// input-gradient GEMMs (dX = dY W) and the single-source 1x1 convolutions / Conv1d k=1 of the UNets.
+//
+//   D[m][n] = act(alpha * sum_k A[m][k] * B[n][k] + bias[n]) + R[m][n]
+//
+// A 512-thread workgroup owns a (16 MB) x 256 tile (MB = 8 or 9: M = 8 x 257 = 2056 rows of the ViT-L/14 batch are 15 tiles of
+// 144 rows -> 240 workgroups for N = 4096, one round on 256 CUs; 128-row tiles would need 17 x 16 = 272).  Every wave owns
+// 16 MB rows x 32 columns (2 MB blocks of v_mfma_f32_16x16x32: 8 MB accumulator registers) and streams the weights of ITS 32
+// columns global -> VGPR in MFMA fragment order (host-packed: engine/ops.py PackedLinear.frag_gemm), prefetched three 32-deep
+// k-steps ahead in a 4-slot register ring: no LDS, no synchronisation on the weight side.  The activation tile goes through
+// LDS, 128 k at a time, double-buffered: ONE barrier per 128-deep chunk (8 MB MFMAs per wave between barriers).  Fragment
+// registers are reloaded in place: block mb's register is dead after its two MFMAs and takes the NEXT step's block mb at once
+// (the reload has (MB - 1) x 32 cycles of MFMAs to land under).  LDS row pitch 288 B = 18 slots of 16 B: the 16 lanes of a
+// ds_read_b128 group (rows i at slot 18 i + k-quarter) hit 16 different slots.
+// Epilogue: two passes (columns 0..127, 128..255) through an fp32 LDS image, written out as whole rows (512 B fp32 / 256 B
+// 16-bit per row): bias, activation, residual (fp32 or 16-bit), fp32 or 16-bit output; with split-K (grid.z) raw fp32 slabs
+// for splitk_reduce_kernel (igemm.hip).
+#include "common.h"
+#include "../../include/perceptor_hip.h"
+
+namespace {
+
+template <typename T, int MB>
+__global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a) {
+  constexpr int TM = 16 * MB, BN = 256, BK = 128, NT = 512;
+  constexpr int ROW = 2 * BK + 32;                     // LDS row pitch (bytes)
+  constexpr int TILE = TM * ROW;
+  constexpr int NPI = (TM * 16 + NT - 1) / NT;         // 16-byte staging pieces per thread per chunk
+  constexpr int SROW = 128 * 4 + 16;                   // epilogue image row: 128 fp32 + pad
+  static_assert(TM * SROW <= 2 * TILE, "epilogue image must fit the staging buffers");
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PMI_STAMPS   // tools/gemm_probe.py --stamps: phase timestamps (100 MHz) per workgroup; a.reserved carries the enable flag
+#define GSTAMP(k) do { if (tid == 0 && a.reserved == 77 && a.splitk <= 1) ((long long*)a.ws)[(int64_t)blockIdx.x * 8 + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define GSTAMP(k) do {} while (0)
+#endif
+  GSTAMP(0);
+  const int tiles_n = a.N / BN, tiles_m = (a.M + TM - 1) / TM;
+  const int logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  // every XCD (own 4 MB L2) gets a contiguous range of tiles: let it walk ALL tiles of the smaller operand for a few of the larger
+  const bool mfast = (int64_t)a.M <= (int64_t)a.N;
+  const int tm = mfast ? logical % tiles_m : logical / tiles_n, tn = mfast ? logical / tiles_m : logical % tiles_n;
+  const int m0 = tm * TM, n0 = tn * BN;
+  const int nch_all = a.K / BK;
+  int c0 = 0, nch = nch_all;
+  if (a.splitk > 1) {
+    const int per = (nch_all + a.splitk - 1) / a.splitk;
+    c0 = blockIdx.z * per;
+    nch = min(per, nch_all - c0);
+  }
+
+  // activation rows of this tile: rows past M fall outside the resource (zeros)
+  const int rows = min(TM, a.M - m0);
+  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc((const u16*)a.A0 + (int64_t)m0 * a.lda0, ((int64_t)(rows - 1) * a.lda0 + a.K) * 2);
+  uint32_t pvo[NPI];                                    // byte offset of this thread's staging pieces inside the tile's rows (k = 0)
+#pragma unroll
+  for (int i = 0; i < NPI; ++i) {
+    const int p = tid + NT * i, r = p >> 4, c16 = p & 15;
+    pvo[i] = r < rows ? (uint32_t)(r * a.lda0 + c16 * 8) * 2u : PMI_BUF_OOB;
+  }
+  // this wave's weight stream: [chunk][k32 (4)][16-column block (2)][lane][8], 8 KB per chunk, contiguous
+  const int64_t wslab = (int64_t)nch_all * 8192;
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc((const char*)a.Bf + (int64_t)(tn * 8 + wid) * wslab, wslab);
+  const uint32_t wvo = (uint32_t)lane * 16u + (uint32_t)c0 * 8192u;
+
+  uint4 pr[NPI];
+  auto load_tile = [&](int chunk, bool live) {
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) pr[i] = buf_load16(rsrc_a, live ? pvo[i] : PMI_BUF_OOB, (uint32_t)(c0 + chunk) * (BK * 2));
+  };
+  auto store_tile = [&](char* buf) {
+#pragma unroll
+    for (int i = 0; i < NPI; ++i) {
+      const int p = tid + NT * i;
+      if (NPI * NT == TM * 16 || p < TM * 16) *(uint4*)(buf + (p >> 4) * ROW + (p & 15) * 16) = pr[i];
+    }
+  };
+
+  f32x4 acc[MB][2];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint4 wq[4][2];                                       // [k32-step slot][16-column block]
+  auto load_w = [&](int slot, int step) {               // global step index inside this workgroup's k range; past the end: zeros
+    const uint32_t vo = wvo + (uint32_t)step * 2048u;
+    const bool live = step < nch * 4;
+    wq[slot][0] = buf_load16(rsrc_w, live ? vo : PMI_BUF_OOB, 0);
+    wq[slot][1] = buf_load16(rsrc_w, live ? vo + 1024u : PMI_BUF_OOB, 0);
+  };
+
+  load_w(0, 0); load_w(1, 1); load_w(2, 2);
+  load_tile(0, true);
+  store_tile(smem);
+  load_tile(nch > 1 ? 1 : 0, nch > 1);                 // chunk 1 travels while chunk 0 is multiplied
+  __syncthreads();
+  GSTAMP(1);
+  const int frag0 = (lane & 15) * ROW + (lane >> 4) * 16;
+  uint4 xf[MB];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) xf[mb] = *(const uint4*)(smem + frag0 + mb * 16 * ROW);
+
+  for (int chunk = 0; chunk < nch; ++chunk) {
+    const char* const pb = smem + (chunk & 1) * TILE;
+    char* const pn = smem + ((chunk + 1) & 1) * TILE;
+    const bool more2 = chunk + 2 < nch;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      load_w((s + 3) & 3, chunk * 4 + s + 3);
+      if (s == 2) store_tile(pn);                       // chunk + 1 (loaded a whole chunk ago) -> the other buffer
+      if (s == 3) {
+        load_tile(more2 ? chunk + 2 : chunk, more2);    // the staging registers are free again: chunk + 2 starts its trip
+        __syncthreads();                                // next tile complete; every wave has issued its last read of the buffer it overwrites next
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const char* const nb = (s < 3 ? pb + (s + 1) * 64 : pn) + frag0;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        acc[mb][0] = T::mfma16(wq[s][0], xf[mb], acc[mb][0]);
+        acc[mb][1] = T::mfma16(wq[s][1], xf[mb], acc[mb][1]);
+        xf[mb] = *(const uint4*)(nb + mb * 16 * ROW);
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();                                      // all fragment reads done: the buffers become the epilogue image
+  GSTAMP(2);
+
+  const bool raw = a.splitk > 1;
+  if (!raw && !a.out_f32 && !(a.R && a.res_f32)) {
+    // ---- epilogue, 16-bit output: ONE pass through a 16-bit image of the whole tile (bias + activation applied on the way in),
+    // written out as 512-byte rows, 16 bytes per lane; a 16-bit residual is added on the way out ----
+    constexpr int HROW = 256 * 2 + 16;
+    static_assert(TM * HROW <= 2 * TILE, "16-bit epilogue image must fit the staging buffers");
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int nl = wid * 32 + cb * 16 + 4 * (lane >> 4);
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.bias) bv = *(const float4*)(a.bias + n0 + nl);
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const f32x4 c = acc[mb][cb];
+        float v[4] = {c[0] * a.alpha + bv.x, c[1] * a.alpha + bv.y, c[2] * a.alpha + bv.z, c[3] * a.alpha + bv.w};
+        if (a.act != PMI_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
+        }
+        *(uint2*)(smem + (mb * 16 + (lane & 15)) * HROW + nl * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
+      }
+    }
+    __syncthreads();
+    const int pc8 = tid & 31, prow = tid >> 5;         // 8 columns (16 B) x rows prow + 16 j
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      const int r = prow + 16 * j, m = m0 + r;
+      if (m >= a.M) continue;
+      uint4 v = *(const uint4*)(smem + r * HROW + pc8 * 16);
+      if (a.R) {
+        float f[8], rr[8];
+        unpack8<T>(v, f);
+        unpack8<T>(*(const uint4*)((const u16*)a.R + (int64_t)m * a.ldr + n0 + pc8 * 8), rr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += rr[e];
+        v = pack8<T>(f);
+      }
+      *(uint4*)((u16*)a.D + (int64_t)m * a.ldd + n0 + pc8 * 8) = v;
+    }
+    GSTAMP(3);
+    return;
+  }
+  // ---- epilogue, fp32 output / fp32 residual / split-K slabs: columns [128 p, 128 p + 128) per pass through an fp32 image ----
+  float* const Dslab = raw ? (float*)a.ws + (int64_t)blockIdx.z * a.M * a.N : nullptr;
+  const int pc = tid & 31, pr0 = tid >> 5;             // write-out role: 4 columns (16 B fp32) x rows pr0 + 16 j
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if ((wid >> 2) == p) {
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+          *(f32x4*)(smem + (mb * 16 + (lane & 15)) * SROW + ((wid & 3) * 32 + cb * 16 + 4 * (lane >> 4)) * 4) = acc[mb][cb];
+    }
+    __syncthreads();
+    const int n = n0 + p * 128 + pc * 4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!raw && a.bias) bv = *(const float4*)(a.bias + n);
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      const int r = pr0 + 16 * j, m = m0 + r;
+      if (m >= a.M) continue;
+      const float4 c = *(const float4*)(smem + r * SROW + pc * 16);
+      float v[4] = {c.x, c.y, c.z, c.w};
+      if (raw) {
+        *(float4*)(Dslab + (int64_t)m * a.N + n) = c;
+        continue;
+      }
+      v[0] = v[0] * a.alpha + bv.x; v[1] = v[1] * a.alpha + bv.y; v[2] = v[2] * a.alpha + bv.z; v[3] = v[3] * a.alpha + bv.w;
+      if (a.act != PMI_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
+      }
+      if (a.R) {
+        if (a.res_f32) {
+          const float4 rr = *(const float4*)((const float*)a.R + (int64_t)m * a.ldr + n);
+          v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+        } else {
+          const uint2 rr = *(const uint2*)((const u16*)a.R + (int64_t)m * a.ldr + n);
+          v[0] += T::to_f((u16)(rr.x & 0xffff)); v[1] += T::to_f((u16)(rr.x >> 16));
+          v[2] += T::to_f((u16)(rr.y & 0xffff)); v[3] += T::to_f((u16)(rr.y >> 16));
+        }
+      }
+      if (a.out_f32) *(float4*)((float*)a.D + (int64_t)m * a.ldd + n) = make_float4(v[0], v[1], v[2], v[3]);
+      else *(uint2*)((u16*)a.D + (int64_t)m * a.ldd + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+  }
+  GSTAMP(3);
+}
+
+template <typename T>
+int launch(const pmi_igemm_args& a, hipStream_t s, int mb) {
+  const int tm = 16 * mb;
+  const dim3 grid(((a.M + tm - 1) / tm) * (a.N / 256), 1, a.splitk > 1 ? a.splitk : 1);
+  if (mb == 9) hipLaunchKernelGGL((gemm_wd_kernel<T, 9>), grid, dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((gemm_wd_kernel<T, 8>), grid, dim3(512), 0, s, a);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+
+}  // namespace
+
+// rows per tile (128 or 144): fewest rounds of 256 workgroups, then least work per workgroup
+int pmi_gemm_wd_tile_rows(const pmi_igemm_args* a, int splitk) {
+  int best = 8;
+  long best_cost = -1;
+  for (int mb = 8; mb <= 9; ++mb) {
+    const long wgs = (long)((a->M + 16 * mb - 1) / (16 * mb)) * (a->N / 256) * (splitk > 1 ? splitk : 1);
+    const long cost = ((wgs + 255) / 256) * mb;
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = mb; }
+  }
+  return 16 * best;
+}
+
+// 1 when the weights-direct GEMM takes this call (plain GEMM with fragment-ordered weights), else the generic kernel runs
+extern "C" int pmi_gemm_wd_eligible(const pmi_igemm_args* a) {
+  if (!a->Bf || a->taps != 1 || a->up || a->stride != 1 || a->batch > 1 || a->C1 != 0 || a->A1) return 0;
+  if (a->nbias || a->stats || a->pro_a || a->res_up || a->split_out) return 0;
+  if ((a->K % 128) || (a->N % 256) || a->K != a->C0 || a->M < 64) return 0;
+  if (a->R && a->res_f32 && !a->out_f32) return 0;
+  return 1;
+}
+
+int pmi_gemm_wd_launch(const pmi_igemm_args* a, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int mb = pmi_gemm_wd_tile_rows(a, a->splitk) / 16;
+  return a->dtype == PMI_DT_BF16 ? launch<BF16>(*a, s, mb) : launch<F16>(*a, s, mb);
+}

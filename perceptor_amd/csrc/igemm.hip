@@ -543,13 +543,12 @@ int launch(const pmi_igemm_args& a, hipStream_t s) {
 
 extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a);
 int pmi_conv3x3_halo_launch(const pmi_igemm_args* a, int cfg, void* stream);
-int pmi_conv3x3_wd_launch(const pmi_igemm_args* a, int cfg, void* stream);   // conv_wd.hip: tile configs 4, 5
+int pmi_conv3x3_wd_launch(const pmi_igemm_args* a, int cfg, void* stream);   // conv_wd.hip: tile configs 4, 6
+extern "C" int pmi_gemm_wd_eligible(const pmi_igemm_args* a);                 // gemm_wd.hip: plain GEMMs with fragment-ordered weights
+int pmi_gemm_wd_tile_rows(const pmi_igemm_args* a, int splitk);
+int pmi_gemm_wd_launch(const pmi_igemm_args* a, void* stream);
 void pmi_conv3x3_allow_wd(int v);
 void pmi_conv3x3_wd_mf16(int v);
-int pmi_gemm_lt(const pmi_igemm_args* a, void* stream);          // gemm_lt.hip: 0 = done by hipBLASLt, 1 = use the generic kernel
-int pmi_gemm_lt_eligible(const pmi_igemm_args* a);
-void pmi_gemm_lt_enable(int v);
-void pmi_gemm_lt_margin(int percent);
 void pmi_conv3x3_force_config(int cfg);
 void pmi_conv3x3_use_glds(int v);
 void pmi_conv3x3_persistent(int v);
@@ -559,7 +558,19 @@ static int g_allow_halo = 1;
 extern "C" int pmi_igemm_splitk(const pmi_igemm_args* a) {
   if (a->batch > 1 || (a->N & 3)) return 1;
   if (g_allow_halo && pmi_conv3x3_halo_config(a) >= 0) return 1;
-  if (pmi_gemm_lt_eligible(a)) return 1;                        // plain GEMM: the library balances its own tiles
+  if (pmi_gemm_wd_eligible(a)) {    // weights-direct GEMM: fill the 256 CUs with (row tile x 256-column) workgroups; >= 2 chunks of 128 per split
+    const int nch = a->K / 128;
+    int best = 1;
+    long best_cost = -1;
+    for (int s = 1; s <= 8 && nch / s >= 4; s *= 2) {
+      const int rows = pmi_gemm_wd_tile_rows(a, s);
+      const long wgs = (long)((a->M + rows - 1) / rows) * (a->N / 256) * s;
+      // rounds x rows x (chunks + fixed prologue / epilogue share); a split pays for its fp32 slabs and the reduce launch
+      const long cost = ((wgs + 255) / 256) * rows * (nch / s + 6) + (s > 1 ? 8L * 144 : 0);
+      if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = s; }
+    }
+    return best;
+  }
   const int tiles = ((a->M + BM - 1) / BM) * ((a->N + BN - 1) / BN);
   const int nk = (a->K + BK - 1) / BK;
   if (tiles >= 384 || nk < 16) return 1;     // 2 workgroups fit per CU: below 384 tiles part of the chip idles through a long K loop
@@ -583,8 +594,6 @@ extern "C" int pmi_set_option(int key, int value) {
   if (key == 1) { pmi_conv3x3_force_config(value); return 0; }
   if (key == 2) { pmi_conv3x3_use_glds(value); return 0; }
   if (key == 3) { pmi_conv3x3_persistent(value); return 0; }
-  if (key == 4) { pmi_gemm_lt_enable(value); return 0; }
-  if (key == 5) { pmi_gemm_lt_margin(value); return 0; }
   if (key == 6) { pmi_conv3x3_allow_wd(value); return 0; }
   if (key == 7) { pmi_conv3x3_wd_mf16(value); return 0; }
   return PMI_ERR_ARG;
@@ -620,9 +629,19 @@ extern "C" int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream) {
   if (a->pro_a && (!a->pro_b || halo < 0)) return PMI_ERR_ARG;
   if (a->stats && a->stats_p != pmi_igemm_stats_rows(a)) return PMI_ERR_ARG;
   if (a->splitk > 1 && (!a->ws || a->batch > 1 || halo >= 0 || (a->N & 3) || a->stats)) return PMI_ERR_ARG;
+  if (pmi_gemm_wd_eligible(a)) {
+    const int rc = pmi_gemm_wd_launch(a, stream);
+    if (rc != PMI_OK || a->splitk <= 1) return rc;
+    hipStream_t s = (hipStream_t)stream;             // split-K: the slabs get bias / activation / residual in the reduce kernel
+    const int64_t work = (int64_t)a->M * (a->N / 4);
+    const int blocks = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
+    if (a->dtype == PMI_DT_BF16) hipLaunchKernelGGL(splitk_reduce_kernel<BF16>, dim3(blocks), dim3(256), 0, s, *a);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<F16>, dim3(blocks), dim3(256), 0, s, *a);
+    PMI_CHECK_LAUNCH();
+    return PMI_OK;
+  }
   if (halo >= 4) return pmi_conv3x3_wd_launch(a, halo, stream);
   if (halo >= 0) return pmi_conv3x3_halo_launch(a, halo, stream);
-  if (pmi_gemm_lt(a, stream) == PMI_OK) return PMI_OK;           // plain GEMMs go to hipBLASLt when it has a kernel for the shape
   hipStream_t s = (hipStream_t)stream;
   return a->dtype == PMI_DT_BF16 ? launch<BF16>(*a, s) : launch<F16>(*a, s);
 }

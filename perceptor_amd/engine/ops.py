@@ -18,6 +18,7 @@ from .._hip import ACT_NONE, DT_F16X2, IgemmArgs, call, ptr
 HALO_ENABLED = True
 SPLITK_ENABLED = True
 WD_ENABLED = True       # weights-direct conv3x3 kernel (csrc/conv_wd.hip) where the shape is eligible
+GEMM_WD_ENABLED = True  # weights-direct GEMM (csrc/gemm_wd.hip) for plain GEMMs
 
 
 def set_halo(enabled: bool) -> None:
@@ -112,6 +113,15 @@ class PackedLinear:
     def K(self):
         return self.taps * self.cin_p
 
+    def frag_gemm(self) -> torch.Tensor:
+        """Fragment order for the weights-direct GEMM (csrc/gemm_wd.hip), 16x16x32 MFMA:
+        [N/32][K/128][32-deep k-step (4)][16-column block (2)][lane = 16*(k quarter) + column][8 k]."""
+        if "gemm" not in self._frag:
+            assert self.taps == 1 and self.n_p % 32 == 0 and self.K % 128 == 0
+            w = self.w.view(self.n_p // 32, 2, 16, self.K // 128, 4, 4, 8)     # nb, cb, r16, chunk, k32, q4, j
+            self._frag["gemm"] = w.permute(0, 3, 4, 1, 5, 2, 6).contiguous()
+        return self._frag["gemm"]
+
     def frag16(self, ck: int) -> torch.Tensor:
         """Fragment order for the 16x16x32 MFMA form of the weights-direct kernel:
         [N/32][Cin/ck][dx][ck/32][dy][16-channel block][lane = 16*(k quarter) + channel][8 k]."""
@@ -185,6 +195,9 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
         a.Bf = 1                       # ask which tile config the weights-direct kernel would run, then hand it that packing
         cfg = _hip.lib().pmi_conv3x3_halo_config(C.byref(a))
         a.Bf = ptr(lin.frag16(64)) if cfg == 6 else ptr(lin.frag(64)) if cfg == 4 else None
+    if GEMM_WD_ENABLED and lin.taps == 1 and not lin.split and not up and stride == 1 and a1 is None and lin.n_p % 256 == 0 and lin.K % 128 == 0 \
+            and nbias is None and not want_stats and prologue is None:
+        a.Bf = ptr(lin.frag_gemm())            # plain GEMM: weights-direct kernel (csrc/gemm_wd.hip)
     if prologue is not None:
         ca, cb, pact = prologue
         if HALO_ENABLED and not lin.split and _hip.lib().pmi_conv3x3_halo_config(C.byref(a)) >= 0:

@@ -53,8 +53,11 @@ def test_ctypes_prototypes_match_header():
         assert len(args) == len(params), f"{name}: header has {len(params)} params, ctypes proto {len(args)}"
         for i, (a, p) in enumerate(zip(args, params)):
             want = _kind(p)
-            if name in ("pmi_igemm", "pmi_conv3x3_halo_config", "pmi_igemm_stats_rows", "pmi_igemm_splitk") and i == 0:
+            if name in ("pmi_igemm", "pmi_conv3x3_halo_config", "pmi_igemm_stats_rows", "pmi_igemm_splitk", "pmi_gemm_wd_eligible") and i == 0:
                 assert a is C.POINTER(_hip.IgemmArgs)
+                continue
+            if name == "pmi_gemm_f32" and i == 0:
+                assert a is C.POINTER(_hip.GemmF32Args)
                 continue
             assert a is want, f"{name} param {i} ({p}): ctypes {a} vs header {want}"
 
@@ -72,7 +75,8 @@ def test_igemm_struct_layout_matches_header():
         for piece in stmt.split(","):
             names.append(re.findall(r"(\w+)\s*$", piece.strip())[0])
     assert names == [f[0] for f in _hip.IgemmArgs._fields_]
-    assert C.sizeof(_hip.IgemmArgs) == 11 * 8 + 25 * 4 + 4 + 8 * 8 + 6 * 4  # 4 bytes of padding before the int64 block
+    # 11 pointers, 25 4-byte fields, 4 bytes of padding before the int64 block, 8 int64, 6 ints, the Bf pointer, split_out / split_in
+    assert C.sizeof(_hip.IgemmArgs) == 11 * 8 + 25 * 4 + 4 + 8 * 8 + 6 * 4 + 8 + 2 * 4
 
 
 def test_product_refuses_cpu_tensors():

@@ -138,6 +138,52 @@ def test_igemm_linear_ragged_and_nbias(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    dict(m=2056, k=1024, n=1024, res="f32", f32=True),          # ViT-L/14 out_proj / c_proj shape: 144-row tiles, fp32 residual stream
+    dict(m=2056, k=1024, n=4096, act=3),                          # c_fc with the exact-GELU epilogue, 16-bit out
+    dict(m=2056, k=4096, n=1024, f32=True),                       # long K, few tiles: split-K slabs + reduce
+    dict(m=300, k=256, n=256, res="16"),                          # ragged last tile, 16-bit residual
+    dict(m=8192, k=512, n=1536),                                  # UNet attention qkv at 32x32
+    dict(m=72, k=128, n=512, f32=True, bias=False),
+])
+def test_gemm_wd(case, dtype):
+    """Weights-direct GEMM (csrc/gemm_wd.hip) against fp32 torch on operands pre-rounded to the compute type."""
+    from perceptor_amd.engine import ops
+    from perceptor_amd._hip import IgemmArgs, dtype_code
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    m, k, n = case["m"], case["k"], case["n"]
+    x = _r(torch.randn(m, k, generator=g), dtype)
+    wt = _r(torch.randn(n, k, generator=g) / k ** 0.5, dtype)
+    b = torch.randn(n, generator=g) * 0.1 if case.get("bias", True) else None
+    ref = x @ wt.T + (b if b is not None else 0)
+    act = case.get("act", 0)
+    if act == 3:
+        ref = F.gelu(ref)
+    td = torch.float16 if dtype == "f16" else torch.bfloat16
+    res = None
+    if case.get("res") == "f32":
+        res = torch.randn(m, n, generator=g)
+        ref = ref + res
+        res = res.to(dev)
+    elif case.get("res") == "16":
+        res = _r(torch.randn(m, n, generator=g), dtype)
+        ref = ref + res
+        res = res.to(td).to(dev)
+    lin = ops.PackedLinear(wt, b, dtype_code(dtype), dev)
+    import ctypes as C
+    from perceptor_amd import _hip
+    out = ops.igemm(x.to(td).to(dev), lin, residual=res, act=act, out_f32=case.get("f32", False))
+    a = IgemmArgs()          # the call above must have gone to the weights-direct kernel
+    a.taps, a.stride, a.M, a.N, a.K, a.C0, a.batch, a.Bf = 1, 1, m, n, k, k, 1, 1
+    assert _hip.lib().pmi_gemm_wd_eligible(C.byref(a)) == 1
+    if case.get("f32"):
+        assert float((out.cpu() - ref).abs().max()) <= 3e-5 * (float(ref.abs().max()) + 1) * (k / 1024) ** 0.5 + 1e-6
+    else:
+        _check(out.cpu(), ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [dict(c=64, g=32, film=True, pool=False), dict(c=256, g=32, film=False, pool=True),
                                   dict(c=96, g=1, film=True, pool=False, affine=False), dict(c=384, g=32, split=256)])
 def test_group_norm(case, dtype):

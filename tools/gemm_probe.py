@@ -8,16 +8,18 @@ from perceptor_amd._hip import dtype_code
 
 p = argparse.ArgumentParser()
 p.add_argument("--shapes", default="2056x4096x1024,2056x4096x64,2056x4096x4096,2056x1024x4096,2048x4096x1024,4096x4096x1024,8192x4096x1024,2056x3072x1024,2056x1024x1024")
-p.add_argument("--iters", type=int, default=50); p.add_argument("--splitk", type=int, default=1); p.add_argument("--stamps", type=int, default=0)
+p.add_argument("--wd", type=int, default=1); p.add_argument("--lt", type=int, default=1); p.add_argument("--f32", type=int, default=0); p.add_argument("--iters", type=int, default=50); p.add_argument("--splitk", type=int, default=1); p.add_argument("--stamps", type=int, default=0)
 a = p.parse_args()
 dev = torch.device("cuda:0")
 dt = dtype_code("bf16")
 ops.SPLITK_ENABLED = bool(a.splitk)
+ops.GEMM_WD_ENABLED = bool(a.wd)
+
 for sh in a.shapes.split(","):
     M, N, K = map(int, sh.split("x"))
     x = torch.randn(M, K).to(torch.bfloat16).to(dev)
     lin = ops.PackedLinear(torch.randn(N, K) / K ** 0.5, torch.zeros(N), dt, dev)
-    out = ops.igemm(x, lin)
+    out = ops.igemm(x, lin, out_f32=bool(a.f32))
     torch.cuda.synchronize()
     best = 1e9
     for r in range(3):
