@@ -72,6 +72,12 @@ typedef struct {
                         * ldd / ldr count 16-bit elements of the 2N-wide rows; 0 = plain.  A split INPUT needs no flag: it is a tensor with 2 Cin
                         * channels whose weights are duplicated along K by the caller.  Generic kernel only (no LDS-halo config). */
   int32_t split_in;    /* 1: the inputs are precise (hi + lo) tensors -> generic kernel only (a fused prologue would act on the two parts separately) */
+  /* fused epilogue extras of the weights-direct GEMM (pmi_gemm_wd_eligible() == 1, 16-bit output, no split-K), the MLP of the CLIP tower
+   * (ruclip/model.py:27-58) and its input gradient: */
+  void* D2;            /* optional second output [M][ldd] 16-bit: the PRE-activation value (c_fc output kept for the backward pass) */
+  const void* aux;     /* optional [M][ldd] 16-bit: the output is multiplied by act'(aux) with act = aux_act (dh * gelu'(h_pre) of the c_proj input gradient) */
+  int32_t aux_act;
+  int32_t reserved3;
 } pmi_igemm_args;
 int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream);
 /* >= 0 when an LDS-halo conv3x3 kernel takes this shape.  csrc/conv3x3.hip: tile config 0: 8x32 px x 256 ch, 1: 16x32 x 128, 2: 8x32 x 128 with two

@@ -43,6 +43,7 @@ class IgemmArgs(C.Structure):
         ("sD_o", C.c_int64), ("sD_i", C.c_int64), ("sR_o", C.c_int64), ("sR_i", C.c_int64),
         ("dtype", C.c_int32), ("ldnb", C.c_int32), ("pro_act", C.c_int32), ("stats_p", C.c_int32), ("splitk", C.c_int32), ("reserved", C.c_int32),
         ("Bf", C.c_void_p), ("split_out", C.c_int32), ("split_in", C.c_int32),
+        ("D2", C.c_void_p), ("aux", C.c_void_p), ("aux_act", C.c_int32), ("reserved3", C.c_int32),
     ]
 
 

@@ -151,15 +151,6 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const u16* __restrict_
   }
 }
 
-__device__ __forceinline__ float act_grad(float x, int act) {
-  switch (act) {
-    case PMI_ACT_RELU: return x > 0.f ? 1.f : 0.f;
-    case PMI_ACT_SILU: { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
-    case PMI_ACT_GELU: return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
-    case PMI_ACT_QUICKGELU: { const float s = 1.f / (1.f + __expf(-1.702f * x)); return s * (1.f + 1.702f * x * (1.f - s)); }
-    default: return 1.f;
-  }
-}
 template <typename T>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const u16* __restrict__ dh, const u16* __restrict__ hpre,
                                                       u16* __restrict__ out, int64_t n8, int act) {

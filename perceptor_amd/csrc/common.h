@@ -129,13 +129,34 @@ __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
                     (uint32_t)T::from_f(c) | ((uint32_t)T::from_f(d) << 16));
 }
 
+// erf(x) by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 rounding level): one v_rcp, one v_exp and a 5-term Horner
+// chain instead of the ~40-instruction libm erff -- the exact-GELU epilogues are VALU-bound otherwise.
+__device__ __forceinline__ float fast_erff(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
+  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float y = 1.f - poly * __expf(-ax * ax);
+  return copysignf(y, x);
+}
+
 __device__ __forceinline__ float act_apply(float x, int act) {
   switch (act) {
     case PMI_ACT_RELU: return x > 0.f ? x : 0.f;
     case PMI_ACT_SILU: return x * __builtin_amdgcn_rcpf(1.f + __expf(-x));       // v_rcp_f32 (1 ulp), no IEEE division sequence
-    case PMI_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+    case PMI_ACT_GELU: return 0.5f * x * (1.f + fast_erff(x * 0.70710678118654752f));
     case PMI_ACT_QUICKGELU: return x * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * x));
     default: return x;
+  }
+}
+
+// d act(x) / dx
+__device__ __forceinline__ float act_grad(float x, int act) {
+  switch (act) {
+    case PMI_ACT_RELU: return x > 0.f ? 1.f : 0.f;
+    case PMI_ACT_SILU: { const float s = 1.f / (1.f + __expf(-x)); return s * (1.f + x * (1.f - s)); }
+    case PMI_ACT_GELU: return 0.5f * (1.f + fast_erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    case PMI_ACT_QUICKGELU: { const float s = 1.f / (1.f + __expf(-1.702f * x)); return s * (1.f + 1.702f * x * (1.f - s)); }
+    default: return 1.f;
   }
 }
 

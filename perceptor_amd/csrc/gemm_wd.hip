@@ -26,9 +26,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
   constexpr int ROW = 2 * BK + 32;                     // LDS row pitch (bytes)
   constexpr int TILE = TM * ROW;
   constexpr int NPI = (TM * 16 + NT - 1) / NT;         // 16-byte staging pieces per thread per chunk
-  constexpr int SROW = 128 * 4 + 16;                   // epilogue image row: 128 fp32 + pad
-  static_assert(TM * SROW <= 2 * TILE, "epilogue image must fit the staging buffers");
-  __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
+  constexpr int HIMG = TM * (256 * 2 + 16);            // one 16-bit epilogue image of the tile
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE > 2 * HIMG ? 2 * TILE : 2 * HIMG];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -140,7 +139,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
     // ---- epilogue, 16-bit output: ONE pass through a 16-bit image of the whole tile (bias + activation applied on the way in),
     // written out as 512-byte rows, 16 bytes per lane; a 16-bit residual is added on the way out ----
     constexpr int HROW = 256 * 2 + 16;
-    static_assert(TM * HROW <= 2 * TILE, "16-bit epilogue image must fit the staging buffers");
+    static_assert(2 * TM * HROW <= 160 * 1024, "the two 16-bit epilogue images (output, pre-activation) must fit the LDS");
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
       const int nl = wid * 32 + cb * 16 + 4 * (lane >> 4);
@@ -150,6 +149,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
       for (int mb = 0; mb < MB; ++mb) {
         const f32x4 c = acc[mb][cb];
         float v[4] = {c[0] * a.alpha + bv.x, c[1] * a.alpha + bv.y, c[2] * a.alpha + bv.z, c[3] * a.alpha + bv.w};
+        if (a.D2) *(uint2*)(smem + TM * HROW + (mb * 16 + (lane & 15)) * HROW + nl * 2) = pack4<T>(v[0], v[1], v[2], v[3]);   // pre-activation image
         if (a.act != PMI_ACT_NONE) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
@@ -164,46 +164,45 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
       const int r = prow + 16 * j, m = m0 + r;
       if (m >= a.M) continue;
       uint4 v = *(const uint4*)(smem + r * HROW + pc8 * 16);
-      if (a.R) {
+      if (a.R || a.aux) {
         float f[8], rr[8];
         unpack8<T>(v, f);
-        unpack8<T>(*(const uint4*)((const u16*)a.R + (int64_t)m * a.ldr + n0 + pc8 * 8), rr);
+        if (a.aux) {
+          unpack8<T>(*(const uint4*)((const u16*)a.aux + (int64_t)m * a.ldd + n0 + pc8 * 8), rr);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] += rr[e];
+          for (int e = 0; e < 8; ++e) f[e] *= act_grad(rr[e], a.aux_act);
+        }
+        if (a.R) {
+          unpack8<T>(*(const uint4*)((const u16*)a.R + (int64_t)m * a.ldr + n0 + pc8 * 8), rr);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += rr[e];
+        }
         v = pack8<T>(f);
       }
       *(uint4*)((u16*)a.D + (int64_t)m * a.ldd + n0 + pc8 * 8) = v;
+      if (a.D2) *(uint4*)((u16*)a.D2 + (int64_t)m * a.ldd + n0 + pc8 * 8) = *(const uint4*)(smem + TM * HROW + r * HROW + pc8 * 16);
     }
     GSTAMP(3);
     return;
   }
-  // ---- epilogue, fp32 output / fp32 residual / split-K slabs: columns [128 p, 128 p + 128) per pass through an fp32 image ----
+  // ---- epilogue, fp32 output / fp32 residual / split-K slabs: straight from the accumulators -- a lane holds 4 consecutive columns
+  // (16 bytes fp32) of one row, the four quarter-waves of a block complete 64-byte runs, the two blocks of a wave a 128-byte line ----
   float* const Dslab = raw ? (float*)a.ws + (int64_t)blockIdx.z * a.M * a.N : nullptr;
-  const int pc = tid & 31, pr0 = tid >> 5;             // write-out role: 4 columns (16 B fp32) x rows pr0 + 16 j
 #pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    if ((wid >> 2) == p) {
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-          *(f32x4*)(smem + (mb * 16 + (lane & 15)) * SROW + ((wid & 3) * 32 + cb * 16 + 4 * (lane >> 4)) * 4) = acc[mb][cb];
-    }
-    __syncthreads();
-    const int n = n0 + p * 128 + pc * 4;
+  for (int cb = 0; cb < 2; ++cb) {
+    const int n = n0 + wid * 32 + cb * 16 + 4 * (lane >> 4);
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!raw && a.bias) bv = *(const float4*)(a.bias + n);
 #pragma unroll
-    for (int j = 0; j < MB; ++j) {
-      const int r = pr0 + 16 * j, m = m0 + r;
+    for (int mb = 0; mb < MB; ++mb) {
+      const int m = m0 + mb * 16 + (lane & 15);
       if (m >= a.M) continue;
-      const float4 c = *(const float4*)(smem + r * SROW + pc * 16);
-      float v[4] = {c.x, c.y, c.z, c.w};
+      const f32x4 c = acc[mb][cb];
       if (raw) {
-        *(float4*)(Dslab + (int64_t)m * a.N + n) = c;
+        *(float4*)(Dslab + (int64_t)m * a.N + n) = make_float4(c[0], c[1], c[2], c[3]);
         continue;
       }
-      v[0] = v[0] * a.alpha + bv.x; v[1] = v[1] * a.alpha + bv.y; v[2] = v[2] * a.alpha + bv.z; v[3] = v[3] * a.alpha + bv.w;
+      float v[4] = {c[0] * a.alpha + bv.x, c[1] * a.alpha + bv.y, c[2] * a.alpha + bv.z, c[3] * a.alpha + bv.w};
       if (a.act != PMI_ACT_NONE) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
@@ -221,7 +220,6 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
       if (a.out_f32) *(float4*)((float*)a.D + (int64_t)m * a.ldd + n) = make_float4(v[0], v[1], v[2], v[3]);
       else *(uint2*)((u16*)a.D + (int64_t)m * a.ldd + n) = pack4<T>(v[0], v[1], v[2], v[3]);
     }
-    __syncthreads();
   }
   GSTAMP(3);
 }
@@ -256,6 +254,7 @@ extern "C" int pmi_gemm_wd_eligible(const pmi_igemm_args* a) {
   if (a->nbias || a->stats || a->pro_a || a->res_up || a->split_out) return 0;
   if ((a->K % 128) || (a->N % 256) || a->K != a->C0 || a->M < 64) return 0;
   if (a->R && a->res_f32 && !a->out_f32) return 0;
+  if ((a->D2 || a->aux) && (a->out_f32 || a->splitk > 1 || (a->R && a->res_f32))) return 0;
   return 1;
 }
 

@@ -146,11 +146,14 @@ class PackedLinear:
 def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
           act: int = ACT_NONE, up: bool = False, stride: int = 1, res_up: bool = False, nbias: Optional[torch.Tensor] = None,
           out_f32: bool = False, out: Optional[torch.Tensor] = None, alpha: float = 1.0, prologue=None,
-          want_stats: bool = False, hw: Optional[int] = None) -> torch.Tensor:
+          want_stats: bool = False, hw: Optional[int] = None, pre_out: Optional[torch.Tensor] = None,
+          act_grad_of: Optional[torch.Tensor] = None, act_grad: int = ACT_NONE) -> torch.Tensor:
     """Convolution (a0 is [N,H,W,C]) or linear (a0 is [M,C]) through pmi_igemm.
 
     prologue = (coef_a [N,Cin], coef_b [N,Cin], act): fused GroupNorm-apply(+FiLM)+activation on the conv input
-    (LDS-halo conv3x3 kernel only); when the shape is not eligible the apply kernel runs first."""
+    (LDS-halo conv3x3 kernel only); when the shape is not eligible the apply kernel runs first.
+    pre_out: 16-bit tensor like the output that receives the PRE-activation value (fused act epilogue keeps the backward's input);
+    act_grad_of / act_grad: the output is multiplied by act'(act_grad_of) -- both only where fused_mlp_epilogues(lin) is True."""
     dt = lin.dt
     conv = a0.ndim == 4
     c0 = a0.shape[-1]
@@ -198,6 +201,8 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
     if GEMM_WD_ENABLED and lin.taps == 1 and not lin.split and not up and stride == 1 and a1 is None and lin.n_p % 256 == 0 and lin.K % 128 == 0 \
             and nbias is None and not want_stats and prologue is None:
         a.Bf = ptr(lin.frag_gemm())            # plain GEMM: weights-direct kernel (csrc/gemm_wd.hip)
+    if pre_out is not None or act_grad_of is not None:
+        a.D2, a.aux, a.aux_act = ptr(pre_out), ptr(act_grad_of), act_grad
     if prologue is not None:
         ca, cb, pact = prologue
         if HALO_ENABLED and not lin.split and _hip.lib().pmi_conv3x3_halo_config(C.byref(a)) >= 0:
@@ -251,6 +256,12 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
         return out
     call("pmi_igemm", C.byref(a))
     return out
+
+
+def fused_mlp_epilogues(lin: PackedLinear, m: int) -> bool:
+    """True when a plain 16-bit-output GEMM of m rows with these weights runs in the weights-direct kernel, whose epilogue can also
+    write the pre-activation value (pre_out) and multiply by an activation gradient (act_grad_of)."""
+    return GEMM_WD_ENABLED and lin.taps == 1 and not lin.split and lin.n_p % 256 == 0 and lin.K % 128 == 0 and m >= 64
 
 
 def bgemm(A: torch.Tensor, B: torch.Tensor, D: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldb: int, ldd: int,

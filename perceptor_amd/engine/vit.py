@@ -167,9 +167,13 @@ class VitEngine:
                 aws = lse = None
             x_mid = ops.igemm(a, blk["out"].fwd, residual=x, out_f32=True)
             h2, _, mr2 = self._ln(x_mid, width, blk["ln2"], m, width)
-            hpre = ops.igemm(h2, blk["fc"].fwd)
-            hact = torch.empty_like(hpre)
-            call("pmi_act_fwd", ptr(hpre), ptr(hact), hpre.numel(), self.act, dt)
+            if ops.fused_mlp_epilogues(blk["fc"].fwd, m):    # activation in the GEMM epilogue; the pre-activation value is kept only for a backward pass
+                hpre = torch.empty((m, blk["fc"].fwd.n_p), dtype=tdt, device=dev) if save else None
+                hact = ops.igemm(h2, blk["fc"].fwd, act=self.act, pre_out=hpre)
+            else:
+                hpre = ops.igemm(h2, blk["fc"].fwd)
+                hact = torch.empty_like(hpre)
+                call("pmi_act_fwd", ptr(hpre), ptr(hact), hpre.numel(), self.act, dt)
             x_out = ops.igemm(hact, blk["pr"].fwd, residual=x_mid, out_f32=True)
             if save:
                 sv["layers"].append(dict(x_in=x, mr1=mr1, qkv=qkv if not fused else None, p=p, aws=aws, lse=lse, a=a if fused else None,
@@ -208,8 +212,11 @@ class VitEngine:
         self._ln_bwd(dy_post, dy_post.shape[1], sv["x_final"], self.ln_post, sv["mr_post"], None, n, width, row_stride=t, g32=g32, g16=g16)
         for blk, L in zip(reversed(self.blocks), reversed(sv["layers"])):
             # ---- MLP branch
-            dh = ops.igemm(g16, blk["pr"].bwd)                                      # [m, 4w]
-            call("pmi_act_bwd", ptr(dh), ptr(L["hpre"]), ptr(dh), dh.numel(), self.act, dt)
+            if ops.fused_mlp_epilogues(blk["pr"].bwd, m):    # dh * act'(h_pre) in the GEMM epilogue
+                dh = ops.igemm(g16, blk["pr"].bwd, act_grad_of=L["hpre"], act_grad=self.act)    # [m, 4w]
+            else:
+                dh = ops.igemm(g16, blk["pr"].bwd)
+                call("pmi_act_bwd", ptr(dh), ptr(L["hpre"]), ptr(dh), dh.numel(), self.act, dt)
             dln2 = ops.igemm(dh, blk["fc"].bwd, out_f32=True)
             gm32, gm16 = self._ln_bwd(dln2, width, L["x_mid"], blk["ln2"], L["mr2"], g32, m, width)
             # ---- attention branch

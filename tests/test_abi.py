@@ -75,8 +75,8 @@ def test_igemm_struct_layout_matches_header():
         for piece in stmt.split(","):
             names.append(re.findall(r"(\w+)\s*$", piece.strip())[0])
     assert names == [f[0] for f in _hip.IgemmArgs._fields_]
-    # 11 pointers, 25 4-byte fields, 4 bytes of padding before the int64 block, 8 int64, 6 ints, the Bf pointer, split_out / split_in
-    assert C.sizeof(_hip.IgemmArgs) == 11 * 8 + 25 * 4 + 4 + 8 * 8 + 6 * 4 + 8 + 2 * 4
+    # 11 pointers, 25 4-byte fields, 4 bytes of padding before the int64 block, 8 int64, 6 ints, the Bf pointer, split_out / split_in, D2 / aux, aux_act / reserved3
+    assert C.sizeof(_hip.IgemmArgs) == 11 * 8 + 25 * 4 + 4 + 8 * 8 + 6 * 4 + 8 + 2 * 4 + 2 * 8 + 2 * 4
 
 
 def test_product_refuses_cpu_tensors():
