@@ -171,6 +171,12 @@ def cpu_baseline(model_name, res, nb, clip_arch, clip_loss, hip_model, dev, seed
     return sec_step, sample, cores, parity
 
 
+def conv_kernel_name(desc):
+    """Kernel a timed 3x3-convolution launch ran in, from its tile config (csrc/conv3x3.hip: pmi_conv3x3_halo_config)."""
+    cfg = int(desc.split(" cfg")[1].split()[0])
+    return "conv3x3_wd_kernel" if cfg >= 4 else "conv3x3_halo_kernel"
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -272,18 +278,25 @@ def main():
         roof = {"bound": "mfma", "achieved": None, "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s", "frac": None, "traffic": None,
                 "step": step_roof}
         if kernel_events:
-            # dominant kernel: every conv3x3_halo_kernel launch of the timed steps, HIP events on the launch stream
-            tot_ms = sum(ev_[0].elapsed_time(ev_[1]) for ev_ in kernel_events)
-            tot_fl = sum(ev_[2] for ev_ in kernel_events)
-            tot_by = sum(ev_[3] for ev_ in kernel_events)
-            k_ach = tot_fl / 1e12 / (tot_ms / 1e3)
-            roof.update({"kernel": "conv3x3_halo_kernel (3x3 convolution as implicit GEMM on MFMA, csrc/conv3x3.hip)",
-                         "achieved": round(k_ach, 2), "frac": round(k_ach / PEAK_TFLOPS[a.dtype], 4),
-                         "launches": len(kernel_events), "avg_ms": round(tot_ms / len(kernel_events), 4),
-                         "share_of_step": round(tot_ms / a.steps / step_ms_dev, 3),
-                         "algorithmic_gflop_per_launch": round(tot_fl / 1e9 / len(kernel_events), 1),
-                         "algorithmic_bytes_per_launch": round(tot_by / len(kernel_events)),
-                         "algorithmic_GBps": round(tot_by / 1e9 / (tot_ms / 1e3), 1)})
+            # dominant kernels: every 3x3-convolution launch of the timed steps (conv3x3_wd_kernel for the 256-multiple Cout
+            # layers, conv3x3_halo_kernel for the rest), HIP events on the launch stream
+            def agg(evs):
+                ms = sum(e[0].elapsed_time(e[1]) for e in evs)
+                fl = sum(e[2] for e in evs)
+                by = sum(e[3] for e in evs)
+                t = fl / 1e12 / (ms / 1e3)
+                return {"achieved": round(t, 2), "frac": round(t / PEAK_TFLOPS[a.dtype], 4), "launches": len(evs),
+                        "avg_ms": round(ms / len(evs), 4), "share_of_step": round(ms / a.steps / step_ms_dev, 3),
+                        "algorithmic_gflop_per_launch": round(fl / 1e9 / len(evs), 1),
+                        "algorithmic_bytes_per_launch": round(by / len(evs)),
+                        "algorithmic_GBps": round(by / 1e9 / (ms / 1e3), 1)}
+            by_kernel = {}
+            for e in kernel_events:
+                by_kernel.setdefault(conv_kernel_name(e[4]), []).append(e)
+            roof.update({"kernel": "3x3 convolution as implicit GEMM on MFMA: conv3x3_wd_kernel (csrc/conv_wd.hip) + "
+                                   "conv3x3_halo_kernel (csrc/conv3x3.hip), all launches of the timed steps"})
+            roof.update(agg(kernel_events))
+            roof["by_kernel"] = {k: agg(v) for k, v in sorted(by_kernel.items())}
             if a.dump_kernels:
                 per = len(kernel_events) // a.steps
                 with open(a.dump_kernels, "w") as f:
@@ -291,12 +304,15 @@ def main():
                         evs = [kernel_events[st * per + k] for st in range(a.steps)]
                         ms = sum(e[0].elapsed_time(e[1]) for e in evs) / a.steps
                         f.write(f"{k:3d} {ms:8.4f} ms {evs[0][2] / 1e9:10.1f} GFLOP {evs[0][3] / 1e6:9.1f} MB {evs[0][2] / 1e9 / ms:8.1f} TFLOP/s {evs[0][3] / 1e6 / ms:8.1f} GB/s {evs[0][4]}\n")
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
-            if a.config == "c5" and os.path.exists(pmc):    # HBM bytes per conv3x3 launch from the committed PMC passes
+            pmc = os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")
+            if a.config == "c5" and a.dtype == "bf16" and os.path.exists(pmc):    # HBM bytes per conv3x3 launch from the committed PMC passes
                 with open(pmc) as f:
-                    roof["traffic"] = json.load(f)["conv3x3_halo_kernel"]["hbm_bytes_per_launch"]
-                roof["traffic_note"] = ("profiles/r01_pmc_hbm.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per conv3x3_halo_kernel launch, "
-                                        "separate rocprofv3 --pmc passes of this command")
+                    rows = json.load(f)
+                rows = [rows[k] for k in ("conv3x3_wd_kernel", "conv3x3_halo_kernel") if k in rows]
+                if rows:
+                    roof["traffic"] = round(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / sum(r["launches"] for r in rows))
+                    roof["traffic_note"] = ("profiles/r02_pmc_hbm.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch, launch-weighted over "
+                                            "conv3x3_wd_kernel and conv3x3_halo_kernel; separate rocprofv3 --pmc passes of this command")
         else:
             roof.update({"achieved": step_roof["achieved"], "frac": step_roof["frac"], "kernel": "whole step (no per-kernel events)"})
         out = {

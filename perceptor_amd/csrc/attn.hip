@@ -59,16 +59,27 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const u16* __restrict__ 
   *(uint4*)(vt + tfrag(bh, Tp >> 5, blockIdx.x, fks, d >> 5, flhi, d & 31)) = out;
 }
 
+// Workgroup -> (row block, head) with all row blocks of a head on ONE XCD (round-robin dispatch puts consecutive linear ids on different
+// XCDs; each XCD has its own L2, so without this every XCD fetches every head's K/V: FETCH_SIZE of vit_attn_bwd was 8x its operands).
+__device__ __forceinline__ void head_xcd_remap(int& bx, int& bh) {
+  const int nx = gridDim.x;
+  const int lin = xcd_remap(blockIdx.x + nx * blockIdx.y, nx * gridDim.y);
+  bh = lin / nx;
+  bx = lin - bh * nx;
+}
+
 template <typename T_>
 __global__ __launch_bounds__(64) void attn_d64_kernel(const u16* __restrict__ q, const u16* __restrict__ k,
                                                       const u16* __restrict__ vt, u16* __restrict__ out, int T, int Tp,
                                                       int heads, float scale) {
   const int lane = threadIdx.x, l31 = lane & 31, lhi = lane >> 5;
-  const int t0 = blockIdx.x * 32, bh = blockIdx.y;
+  int bx, bh;
+  head_xcd_remap(bx, bh);
+  const int t0 = bx * 32;
   const int ntb = Tp >> 5;
   uint4 qf[4];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const uint4*)(q + rfrag(bh, ntb, blockIdx.x, kk, lhi, l31));
+  for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const uint4*)(q + rfrag(bh, ntb, bx, kk, lhi, l31));
 
   f32x16 o0, o1;
 #pragma unroll
@@ -236,11 +247,13 @@ template <typename T_>
 __global__ __launch_bounds__(64) void vit_attn_fwd_kernel(const u16* __restrict__ q, const u16* __restrict__ k, const u16* __restrict__ vt,
                                                           u16* __restrict__ out, float* __restrict__ lse, int T, int Tp, int heads, float scale) {
   const int lane = threadIdx.x, l31 = lane & 31, lhi = lane >> 5;
-  const int t0 = blockIdx.x * 32, bh = blockIdx.y;
+  int bx, bh;
+  head_xcd_remap(bx, bh);
+  const int t0 = bx * 32;
   const int ntb = Tp >> 5;
   uint4 qf[4];
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const uint4*)(q + rfrag(bh, ntb, blockIdx.x, kk, lhi, l31));
+  for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const uint4*)(q + rfrag(bh, ntb, bx, kk, lhi, l31));
   f32x16 o0, o1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
@@ -430,8 +443,10 @@ __global__ __launch_bounds__(64) void vit_attn_bwd_kernel(const u16* __restrict_
                                                           const u16* __restrict__ d_o, const u16* __restrict__ d_ot,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           u16* __restrict__ dqkv, int T, int Tp, int heads, float scale) {
-  if (blockIdx.z == 0) vit_attn_dkdv_body<T_>(q, k, v, qt, d_o, d_ot, lse, delta, dqkv, T, Tp, heads, scale, blockIdx.x, blockIdx.y);
-  else vit_attn_dq_body<T_>(q, k, v, kt, d_o, lse, delta, dqkv, T, Tp, heads, scale, blockIdx.x, blockIdx.y);
+  int bx, bh;
+  head_xcd_remap(bx, bh);
+  if (blockIdx.z == 0) vit_attn_dkdv_body<T_>(q, k, v, qt, d_o, d_ot, lse, delta, dqkv, T, Tp, heads, scale, bx, bh);
+  else vit_attn_dq_body<T_>(q, k, v, kt, d_o, lse, delta, dqkv, T, Tp, heads, scale, bx, bh);
 }
 
 }  // namespace

@@ -28,7 +28,7 @@ def set_halo(enabled: bool) -> None:
     _hip.lib().pmi_set_option(0, int(enabled))
 
 
-# bench.py sets this to a list to time every conv3x3_halo_kernel launch with HIP events on the launch stream
+# bench.py sets this to a list to time every 3x3-convolution launch (conv3x3_wd_kernel, conv3x3_halo_kernel) with HIP events on the launch stream
 KERNEL_EVENTS = None
 GEMM_TRACE = None    # tools/gemm_trace.py: list collecting (desc, flops, ev0, ev1) of every pmi_igemm launch
 DEBUG_WS = None      # tools/conv_probe.py --stamps: int64 buffer the PMI_STAMPS build of conv3x3.hip writes phase timestamps to
