@@ -184,6 +184,26 @@ int pmi_lincomb2(const float* a, const float* b, const float* ca, const float* c
                  int64_t chw, pmi_stream_t s);
 int pmi_clamp(const float* a, const float* lo, const float* hi, float* out, int N, int64_t chw, pmi_stream_t s);
 
+/* ---- Predictions variants and clamp_with_grad (csrc/sampling.hip), fp32, one row per sample ------------------
+ * pmi_quantile_abs: out[n] = torch.quantile(|x[n, :]|, q) (linear interpolation), radix select -- replaces the quantile in
+ *   Predictions.dynamic_threshold (guided_diffusion/predictions.py:156-172 ; velocity_diffusion/predictions.py:148-164).
+ * pmi_randn: standard-normal noise for step(eta>0) / resample_noise / noisy_reverse_step (predictions.py:61-98,126-145), replacing
+ *   torch.randn_like.  Philox4x32-10 + Box-Muller; element e of the draw (seed, stream) is a function of (seed, stream,
+ *   first_element + e) only, so a rank that holds samples [r0, r1) of a batch passes first_element = r0 * chw and gets the same values
+ *   as a single process.  pmi_philox4x32_10 exposes the raw generator for known-answer tests.
+ * pmi_sort_rows / pmi_wasserstein: Predictions.wasserstein_distance / wasserstein_square_distance (predictions.py:184-198):
+ *   rows sorted ascending into work[rows][pmi_sort_rows_padded(n)] (bitonic network, +inf padding), then
+ *   out[0] = mean |sorted - Normal(0,1).icdf(linspace(0.5/n, 1-0.5/n, n))|^power (power 1 or 2); partial = 1024 floats of workspace.
+ * pmi_clamp_grad: backward of clamp_with_grad (transforms/clamp_with_grad.py:8-23) with per-sample bounds:
+ *   out = grad * (grad * (x - clamp(x, lo, hi)) >= 0).                                                                          */
+int pmi_quantile_abs(const float* x, float* out, int N, int64_t n, float q, pmi_stream_t s);
+int pmi_randn(float* out, int64_t n, int64_t first_element, int64_t seed_bits, int64_t stream_bits, pmi_stream_t s);
+int pmi_philox4x32_10(uint32_t* out4, int64_t counter_lo, int64_t counter_hi, int64_t key, pmi_stream_t s);
+int pmi_sort_rows_padded(int64_t n);
+int pmi_sort_rows(const float* x, float* work, int rows, int64_t n, pmi_stream_t s);
+int pmi_wasserstein(const float* sorted, int rows, int64_t n, int power, float* partial, float* out, pmi_stream_t s);
+int pmi_clamp_grad(const float* x, const float* grad, const float* lo, const float* hi, float* out, int N, int64_t chw, pmi_stream_t s);
+
 /* ---- CLIP guidance path (forward + input-gradient) ---------------------------------------
  * ViT arithmetic: open-clip-torch 2.0.2 visual tower == OpenAI-CLIP VisionTransformer, in-tree copy
  * ruclip/model.py:11-131; wrapper models/open_clip.py:109-123; loss losses/clip/clip.py:89-99.

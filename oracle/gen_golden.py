@@ -82,6 +82,52 @@ def gen_sampling():
     save("sampling", **out)
 
 
+def gen_sampling2():
+    """Stochastic and sort/quantile-based Predictions variants (row f3) and clamp_with_grad, from the reference classes.  The reference
+    draws with torch.randn_like; here that name is bound to a function returning committed noise arrays (in call order), so the
+    fixture pins the ARITHMETIC around the noise -- the product's own generator is pinned by known-answer vectors instead."""
+    su = R.ref("models.guided_diffusion.script_util")
+    P = R.ref("models.guided_diffusion.predictions").Predictions
+    VP = R.ref("models.velocity_diffusion.predictions").Predictions
+    cwg = R.ref("transforms.clamp_with_grad")
+    diffusion = su.create_gaussian_diffusion(steps=1000, learn_sigma=True, noise_schedule="linear")
+    alphas = torch.from_numpy(diffusion.alphas_cumprod).sqrt().float()
+    sigmas = (1 - torch.from_numpy(diffusion.alphas_cumprod)).sqrt().float()
+    img = seeded_noise((2, 3, 16, 16), 21) * 0.3 + 0.5
+    eps = seeded_noise((2, 3, 16, 16), 22)
+    noise = seeded_noise((2, 3, 16, 16), 24)
+    fi, ti, hi = torch.tensor([900, 37]), torch.tensor([850, 0]), torch.tensor([950, 400])
+    real = torch.randn_like
+    torch.randn_like = lambda t, **kw: noise.to(t)
+    try:
+        p = P(from_diffused_images=img, from_indices=fi, predicted_noise=eps, schedule_alphas=alphas, schedule_sigmas=sigmas)
+        out = dict(noise=noise, hi=hi,
+                   eps_step_eta=p.step(ti, eta=0.7), eps_resample_noise=p.resample_noise(ti), eps_resample=p.resample(ti),
+                   eps_noisy_reverse=p.noisy_reverse_step(hi),
+                   eps_wasserstein=torch.stack([p.wasserstein_distance(), p.wasserstein_square_distance()]))
+        ft, tt, ht = torch.tensor([0.9, 0.05]), torch.tensor([0.8, 0.01]), torch.tensor([0.95, 0.4])
+        v = VP(from_diffused_images=img, from_ts=ft, velocities=eps)
+        out.update(ht=ht, v_step_eta=v.step(tt, eta=0.7), v_resample_noise=v.resample_noise(tt), v_resample=v.resample(tt),
+                   v_noisy_reverse=v.noisy_reverse_step(ht), v_reverse=VP(from_diffused_images=img, from_ts=tt, velocities=eps).reverse_step(ft),
+                   v_wasserstein=torch.stack([v.wasserstein_distance(), v.wasserstein_square_distance()]))
+    finally:
+        torch.randn_like = real
+    # a longer row for the sort / quantile kernels (crosses the 4096-element LDS block of the bitonic network), heavy ties included
+    big = seeded_noise((3, 3, 40, 50), 25)
+    big[1] = (big[1] * 4).round() / 4
+    pb = P(from_diffused_images=big * 0.2 + 0.5, from_indices=torch.tensor([500, 20, 999]), predicted_noise=big, schedule_alphas=alphas,
+           schedule_sigmas=sigmas)
+    out.update(big=big, big_wasserstein=torch.stack([pb.wasserstein_distance(), pb.wasserstein_square_distance()]),
+               big_quantiles=torch.stack([torch.quantile(big.flatten(1).abs(), q, dim=1) for q in (0.0, 0.5, 0.95, 0.999, 1.0)]))
+    # clamp_with_grad forward and backward (transforms/clamp_with_grad.py:8-23)
+    x = (seeded_noise((2, 3, 16, 16), 26) * 0.8 + 0.5).requires_grad_()
+    g = seeded_noise((2, 3, 16, 16), 27)
+    y = cwg.clamp_with_grad(x, 0.0, 1.0)
+    y.backward(g)
+    out.update(cwg_x=x.detach(), cwg_g=g, cwg_y=y.detach(), cwg_dx=x.grad)
+    save("sampling2", **out)
+
+
 ADM_TINY = {
     "a": dict(image_size=64, num_channels=32, num_res_blocks=1, channel_mult="1,2,2", learn_sigma=True,
               attention_resolutions="32,16", num_head_channels=16, use_scale_shift_norm=True, resblock_updown=True),

@@ -95,3 +95,83 @@ def v_predicted_noise(images, v, t_f):
 def v_step(images, v, t_f, t_t):
     a, s = t_to_alpha_sigma(t_t)
     return (v_denoised_xs(images, v, t_f) * _b(a) + v_predicted_noise(images, v, t_f) * _b(s) + 1) / 2
+
+
+# ---- stochastic / sort / quantile variants (row f3) -----------------------
+# Mirrors guided_diffusion/predictions.py:61-98 (eta > 0), :116-145 (resample, noisy_reverse_step), :156-172 (dynamic_threshold),
+# :184-198 (wasserstein_*); velocity_diffusion/predictions.py:68-105,119-147,148-164,187-200.  The noise is an argument here (the
+# reference draws it with torch.randn_like).  Pinned against tests/golden/sampling2.npz.
+def step_eta(x0, eps, a_f, s_f, a_t, s_t, eta, noise, decode=True):
+    ddim_sigma = eta * (_b(s_t) ** 2 / _b(s_f) ** 2).sqrt() * (1 - _b(a_f) ** 2 / _b(a_t) ** 2).sqrt()
+    adjusted = (_b(s_t) ** 2 - ddim_sigma**2).sqrt()
+    xs = x0 * _b(a_t) + eps * adjusted + noise * ddim_sigma
+    return (xs + 1) / 2 if decode else xs
+
+
+def resample_noise(eps, s_f, s_r, noise):
+    return (_b(s_r) * eps + (_b(s_f) ** 2 - _b(s_r) ** 2).sqrt() * noise) / _b(s_f)
+
+
+def resample(x0, eps, a_f, s_f, s_r, noise):
+    return (x0 * _b(a_f) + resample_noise(eps, s_f, s_r, noise) * _b(s_f) + 1) / 2
+
+
+def noisy_reverse_step(x0, eps, s_f, a_t, s_t, noise):
+    return (x0 * _b(a_t) + _b(s_f) * eps + (_b(s_t) ** 2 - _b(s_f) ** 2).sqrt() * noise + 1) / 2
+
+
+def quantile_abs(x, q):
+    return torch.quantile(x.flatten(start_dim=1).abs(), q, dim=1)
+
+
+def wasserstein(pred, power):
+    s = pred.flatten(start_dim=1).sort(dim=1)[0]
+    n = s.shape[1]
+    expected = torch.distributions.Normal(0, 1).icdf(torch.linspace(0.5 / n, 1 - 0.5 / n, n))
+    d = (s - expected[None]).abs()
+    return (d if power == 1 else d.square()).mean()
+
+
+def clamp_with_grad_backward(x, grad, lo, hi):
+    """transforms/clamp_with_grad.py:16-23"""
+    return grad * (grad * (x - x.clamp(lo, hi)) >= 0)
+
+
+# ---- the product's counter-based generator, restated (csrc/sampling.hip: pmi_randn) ----------------------------------------
+# Philox4x32-10 as published (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123 v1.x),
+# pinned by that library's known-answer vectors (tests/test_oracle_golden.py).  There is no reference counterpart: the reference calls
+# torch.randn_like, whose values are not reproducible across devices.
+_M0, _M1, _W0, _W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+
+
+def philox4x32_10(counter, key):
+    """counter: uint32 array [..., 4]; key: (k0, k1).  Returns uint32 [..., 4]."""
+    c = [np.asarray(counter[..., i], dtype=np.uint64) for i in range(4)]
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = np.uint64(_M0) * c[0], np.uint64(_M1) * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ k0, p1 & mask, (p0 >> np.uint64(32)) ^ c[3] ^ k1, p0 & mask]
+        k0, k1 = (k0 + np.uint64(_W0)) & mask, (k1 + np.uint64(_W1)) & mask
+    return np.stack(c, axis=-1).astype(np.uint32)
+
+
+def device_randn(shape, seed, stream, first_element=0):
+    """Element e of the draw (seed, stream): lane (g & 3) of Philox block (g >> 2), g = first_element + e; Box-Muller on 23-bit uniforms."""
+    n = int(np.prod(shape))
+    g = np.arange(first_element, first_element + n, dtype=np.uint64)
+    blk = g >> np.uint64(2)
+    ctr = np.stack([blk & np.uint64(0xFFFFFFFF), blk >> np.uint64(32),
+                    np.full_like(blk, stream & 0xFFFFFFFF), np.full_like(blk, (stream >> 32) & 0xFFFFFFFF)], axis=-1)
+    r = philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF))
+    lane = (g & np.uint64(3)).astype(np.int64)
+    pair = lane >> 1
+    r0 = np.take_along_axis(r, (pair * 2)[:, None], axis=1)[:, 0]
+    r1 = np.take_along_axis(r, (pair * 2 + 1)[:, None], axis=1)[:, 0]
+    scale = np.float32(2.0**-23)
+    u1 = ((r0 >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * scale
+    u2 = ((r1 >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * scale
+    rad = np.sqrt(np.float32(-2.0) * np.log(u1))
+    th = np.float32(6.283185307179586) * u2
+    z = np.where((lane & 1) == 0, rad * np.cos(th), rad * np.sin(th)).astype(np.float32)
+    return torch.from_numpy(z.reshape(tuple(shape)))

@@ -89,6 +89,14 @@ _PROTOS = {
     "pmi_guided_update": ([_P, _P, _P, _F, _F, _P, _I, _L, _P],),
     "pmi_lincomb2": ([_P, _P, _P, _P, _P, _P, _I, _L, _P],),
     "pmi_clamp": ([_P, _P, _P, _P, _I, _L, _P],),
+    # Predictions variants, clamp_with_grad (sampling.hip)
+    "pmi_quantile_abs": ([_P, _P, _I, _L, _F, _P],),
+    "pmi_randn": ([_P, _L, _L, _L, _L, _P],),
+    "pmi_philox4x32_10": ([_P, _L, _L, _L, _P],),
+    "pmi_sort_rows_padded": ([_L],),
+    "pmi_sort_rows": ([_P, _P, _I, _L, _P],),
+    "pmi_wasserstein": ([_P, _I, _L, _I, _P, _P, _P],),
+    "pmi_clamp_grad": ([_P, _P, _P, _P, _P, _I, _L, _P],),
     # CLIP path (clip.hip)
     "pmi_layernorm_fwd": ([_P, _I, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],),
     "pmi_layernorm_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],),

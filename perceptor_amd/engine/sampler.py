@@ -69,3 +69,99 @@ def guided_update(pred, grad, s_f, scale: float, clamp_value: float):
     vs = _vec(s_f, n, pred.device)
     call("pmi_guided_update", ptr(pred), ptr(grad), ptr(vs), float(scale), float(clamp_value), ptr(out), n, chw)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------- device RNG
+class DeviceRng:
+    """Counter-based normal noise for the stochastic Predictions variants (csrc/sampling.hip: Philox4x32-10 + Box-Muller).
+
+    Seeding contract: every draw takes a fresh 128-bit (seed, stream) pair -- two int64 from torch's default CPU generator (or from the
+    generator installed by ``rng.manual_seed``) -- and element e of the draw is a function of (seed, stream, sample_offset * chw + e) only.
+      * ``torch.manual_seed(s)`` therefore makes a run reproducible exactly as it does for the reference's ``torch.randn_like`` calls
+        (the VALUES differ from torch's device generator, which no script can rely on across devices or torch versions anyway), and
+        ranks that seed alike draw alike;
+      * the values do not depend on launch geometry, device count or how the batch is split: a process that holds samples
+        [sample_offset, sample_offset + N_local) of the global batch gets the noise a single process would have drawn for them.
+    """
+
+    def __init__(self):
+        self.generator = None          # None: torch's default CPU generator
+        self.sample_offset = 0
+
+    def manual_seed(self, seed: int) -> "DeviceRng":
+        self.generator = torch.Generator().manual_seed(int(seed))
+        return self
+
+    def next_key(self):
+        k = torch.randint(-(1 << 63), (1 << 63) - 1, (2,), dtype=torch.int64, generator=self.generator)
+        return int(k[0]), int(k[1])
+
+    def randn_like(self, t: torch.Tensor) -> torch.Tensor:
+        if not t.is_cuda:
+            raise RuntimeError("perceptor_amd sampler updates run on a HIP device only (no CPU fallback)")
+        seed, stream = self.next_key()
+        out = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+        chw = out[0].numel() if out.ndim > 1 else 1
+        call("pmi_randn", ptr(out), out.numel(), self.sample_offset * chw, seed, stream)
+        return out
+
+
+def _i64(v: int) -> int:
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+rng = DeviceRng()
+
+
+def randn_like(t: torch.Tensor) -> torch.Tensor:
+    return rng.randn_like(t)
+
+
+# ------------------------------------------------------------------------------------------- quantile / sort-based statistics
+def quantile_abs(x: torch.Tensor, q: float) -> torch.Tensor:
+    """torch.quantile(x.flatten(1).abs(), q, dim=1) by radix select (no sort, no |x| temporary)."""
+    x = _prep(x)
+    n = x.shape[0]
+    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    call("pmi_quantile_abs", ptr(x), ptr(out), n, x[0].numel(), float(q))
+    return out
+
+
+def sort_rows(x: torch.Tensor) -> torch.Tensor:
+    """Each sample's elements sorted ascending: [N, n] view of a padded work buffer."""
+    from .._hip import lib
+    x = _prep(x)
+    rows, n = x.shape[0], x[0].numel()
+    npad = lib().pmi_sort_rows_padded(n)
+    if npad < 0:
+        raise RuntimeError("pmi_sort_rows: row length out of range")
+    work = torch.empty(rows, npad, dtype=torch.float32, device=x.device)
+    call("pmi_sort_rows", ptr(x), ptr(work), rows, n)
+    return work[:, :n]
+
+
+def wasserstein(x: torch.Tensor, power: int) -> torch.Tensor:
+    """mean |sort(x_n) - Normal(0,1).icdf(linspace(0.5/n, 1-0.5/n, n))|^power over all samples (0-dim tensor)."""
+    from .._hip import lib
+    x = _prep(x)
+    rows, n = x.shape[0], x[0].numel()
+    npad = lib().pmi_sort_rows_padded(n)
+    if npad < 0:
+        raise RuntimeError("pmi_sort_rows: row length out of range")
+    work = torch.empty(rows, npad, dtype=torch.float32, device=x.device)
+    partial = torch.empty(1024, dtype=torch.float32, device=x.device)
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    call("pmi_sort_rows", ptr(x), ptr(work), rows, n)
+    call("pmi_wasserstein", ptr(work), rows, n, int(power), ptr(partial), ptr(out))
+    return out[0]
+
+
+def clamp_grad(x, grad, lo, hi):
+    """Backward of clamp_with_grad: grad * (grad * (x - clamp(x, lo, hi)) >= 0)."""
+    x, grad = _prep(x), _prep(grad)
+    n, chw = x.shape[0], x[0].numel()
+    out = torch.empty_like(x)
+    vlo, vhi = _vec(lo, n, x.device), _vec(hi, n, x.device)
+    call("pmi_clamp_grad", ptr(x), ptr(grad), ptr(vlo), ptr(vhi), ptr(out), n, chw)
+    return out

@@ -160,7 +160,7 @@ class GuidedDiffusion(torch.nn.Module):
         from ...engine import sampler
         indices = self.indices(indices)
         if noise is None:
-            noise = torch.randn_like(denoised_images)
+            noise = sampler.randn_like(denoised_images)
         a, s = self.schedule_alphas[indices], self.schedule_sigmas[indices]
         # decode(encode(img)*alpha + noise*sigma) = img*alpha + noise*sigma/2 + (1-alpha)/2
         return sampler.lincomb2(denoised_images, a, noise, s / 2, (1 - a) / 2)

@@ -2,7 +2,8 @@
 
 Same fields, properties, method names, argument meaning and error behaviour as the reference
 (perceptor/models/guided_diffusion/predictions.py:9-198); the arithmetic runs in the fused HIP
-kernels of csrc/elementwise.hip (pmi_ddim_eps_step, pmi_guided_update, pmi_lincomb2, pmi_clamp)
+kernels of csrc/elementwise.hip (pmi_ddim_eps_step, pmi_guided_update, pmi_lincomb2, pmi_clamp) and csrc/sampling.hip
+(pmi_quantile_abs, pmi_randn, pmi_sort_rows, pmi_wasserstein)
 instead of ~10 small PyTorch ops per call.  Per-sample scalars (alpha/sigma gathers) stay in torch.
 """
 from __future__ import annotations
@@ -73,7 +74,7 @@ class Predictions(FrozenRecord):
             ddim_sigma = eta * (st**2 / sf**2).sqrt() * (1 - af**2 / at**2).sqrt()
             adjusted = (st**2 - ddim_sigma**2).sqrt()
             nxt, _ = sampler.ddim_step("eps", self.from_diffused_images, self.predicted_noise, af, sf, at, adjusted)
-            noise = torch.randn_like(nxt)
+            noise = sampler.randn_like(nxt)
             return sampler.lincomb2(nxt, 1.0, noise, ddim_sigma / 2)
         nxt, _ = sampler.ddim_step("eps", self.from_diffused_images, self.predicted_noise, af, sf, at, st)
         return nxt
@@ -95,7 +96,7 @@ class Predictions(FrozenRecord):
         if (torch.as_tensor(self.from_indices).cpu() < torch.as_tensor(resample_indices).cpu()).any():
             raise ValueError("from_indices must be greater than resample_indices")
         sf, sr = self._s(self.from_indices), self._s(resample_indices)
-        return sampler.lincomb2(self.predicted_noise, sr / sf, torch.randn_like(self.predicted_noise), (sf**2 - sr**2).sqrt() / sf)
+        return sampler.lincomb2(self.predicted_noise, sr / sf, sampler.randn_like(self.predicted_noise), (sf**2 - sr**2).sqrt() / sf)
 
     def resample(self, resample_indices):
         """Harmonizing resampling (RePaint).   predictions.py:116-136"""
@@ -106,7 +107,7 @@ class Predictions(FrozenRecord):
     def noisy_reverse_step(self, to_indices):
         at, st = self._a(to_indices), self._s(to_indices)
         sf = self._s(self.from_indices)
-        noise_sigma = sampler.lincomb2(self.predicted_noise, sf, torch.randn_like(self.predicted_noise), (st**2 - sf**2).sqrt())
+        noise_sigma = sampler.lincomb2(self.predicted_noise, sf, sampler.randn_like(self.predicted_noise), (st**2 - sf**2).sqrt())
         return sampler.lincomb2(self.denoised_xs, at / 2, noise_sigma, 0.5, 0.5)
 
     def guided(self, guiding, guidance_scale=0.5, clamp_value=1e-6) -> "Predictions":
@@ -114,10 +115,10 @@ class Predictions(FrozenRecord):
             self.predicted_noise, guiding, self._s(self.from_indices), guidance_scale, clamp_value))
 
     def dynamic_threshold(self, quantile=0.95) -> "Predictions":
-        """Imagen thresholding (predictions.py:156-172).  The per-sample quantile is a torch op (selection kernel
-        is a 'next' row); unlike the reference the threshold broadcasts correctly for N > 1."""
+        """Imagen thresholding (predictions.py:156-172).  Per-sample quantile of |x0| by radix select (csrc/sampling.hip); unlike the
+        reference, whose [N] threshold broadcasts against W, the threshold applies per sample for N > 1."""
         xs = self.denoised_xs
-        thr = torch.quantile(xs.flatten(start_dim=1).abs(), quantile, dim=1).clamp(min=1.0)
+        thr = sampler.quantile_abs(xs, quantile).clamp(min=1.0)
         return self.forced_denoised_images(sampler.lincomb2(sampler.clamp(xs, -thr, thr), 0.5, cc=0.5))
 
     def forced_denoised_images(self, denoised_images) -> "Predictions":
@@ -131,13 +132,8 @@ class Predictions(FrozenRecord):
         return self.replace(predicted_noise=predicted_noise)
 
     def _wasserstein(self, power):
-        # sort-based statistic (predictions.py:184-198): torch ops, 'next' row SURVEY §8f-3
-        s = self.predicted_noise.flatten(start_dim=1).sort(dim=1)[0]
-        n = s.shape[1]
-        pts = torch.linspace(0.5 / n, 1 - 0.5 / n, n)
-        exp = torch.distributions.Normal(0, 1).icdf(pts)[None].to(s)
-        d = (s - exp).abs()
-        return (d if power == 1 else d.square()).mean()
+        # sort + comparison with the normal quantiles (predictions.py:184-198): bitonic sort and fused statistic, csrc/sampling.hip
+        return sampler.wasserstein(self.predicted_noise, power)
 
     def wasserstein_distance(self):
         return self._wasserstein(1)

@@ -72,7 +72,7 @@ class Predictions(FrozenRecord):
             ddim_sigma = eta * (st**2 / sf**2).sqrt() * (1 - af**2 / at**2).sqrt()
             adjusted = (st**2 - ddim_sigma**2).sqrt()
             nxt, _ = sampler.ddim_step("v", self.from_diffused_images, self.velocities, af, sf, at, adjusted)
-            return sampler.lincomb2(nxt, 1.0, torch.randn_like(nxt), ddim_sigma / 2)
+            return sampler.lincomb2(nxt, 1.0, sampler.randn_like(nxt), ddim_sigma / 2)
         nxt, _ = sampler.ddim_step("v", self.from_diffused_images, self.velocities, af, sf, at, st)
         return nxt
 
@@ -89,7 +89,7 @@ class Predictions(FrozenRecord):
         if (torch.as_tensor(self.from_ts).cpu() < torch.as_tensor(resample_ts).cpu()).any():
             raise ValueError("from_ts must be greater than resample_ts")
         sf, sr = self._s(self.from_ts), self._s(resample_ts)
-        return sampler.lincomb2(self.predicted_noise, sr / sf, torch.randn_like(self.velocities), (sf**2 - sr**2).sqrt() / sf)
+        return sampler.lincomb2(self.predicted_noise, sr / sf, sampler.randn_like(self.velocities), (sf**2 - sr**2).sqrt() / sf)
 
     def resample(self, resample_ts):
         xs = sampler.lincomb2(self.denoised_xs, self._a(self.from_ts), self.resample_noise(resample_ts), self._s(self.from_ts))
@@ -97,7 +97,7 @@ class Predictions(FrozenRecord):
 
     def noisy_reverse_step(self, to_ts):
         at, st, sf = self._a(to_ts), self._s(to_ts), self._s(self.from_ts)
-        ns = sampler.lincomb2(self.predicted_noise, sf, torch.randn_like(self.velocities), (st**2 - sf**2).sqrt())
+        ns = sampler.lincomb2(self.predicted_noise, sf, sampler.randn_like(self.velocities), (st**2 - sf**2).sqrt())
         return sampler.lincomb2(self.denoised_xs, at / 2, ns, 0.5, 0.5)
 
     def guided(self, guiding, guidance_scale=0.5, clamp_value=1e-6) -> "Predictions":
@@ -105,7 +105,7 @@ class Predictions(FrozenRecord):
 
     def dynamic_threshold(self, quantile=0.95) -> "Predictions":
         xs = self.denoised_xs
-        thr = torch.quantile(xs.flatten(start_dim=1).abs(), quantile, dim=1).clamp(min=1.0)   # torch op: 'next' row §8f-3
+        thr = sampler.quantile_abs(xs, quantile).clamp(min=1.0)      # radix select, csrc/sampling.hip
         clamped = sampler.clamp(xs, -thr, thr)
         return self.forced_denoised_images(sampler.lincomb2(clamped, 0.5 / thr, cc=0.5))          # decode(xs / thr)
 
@@ -131,11 +131,7 @@ class Predictions(FrozenRecord):
         return self.replace(velocities=sampler.lincomb2(predicted_noise, a, x0, -s))
 
     def _wasserstein(self, power):
-        s = self.predicted_noise.flatten(start_dim=1).sort(dim=1)[0]     # sort: torch op, 'next' row §8f-3
-        n = s.shape[1]
-        exp = torch.distributions.Normal(0, 1).icdf(torch.linspace(0.5 / n, 1 - 0.5 / n, n))[None].to(s)
-        d = (s - exp).abs()
-        return (d if power == 1 else d.square()).mean()
+        return sampler.wasserstein(self.predicted_noise, power)      # bitonic sort + fused statistic, csrc/sampling.hip
 
     def wasserstein_distance(self):
         return self._wasserstein(1)

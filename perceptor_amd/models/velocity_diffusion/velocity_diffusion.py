@@ -159,7 +159,7 @@ class VelocityDiffusion(torch.nn.Module):
         if isinstance(ts, float) or ts.ndim == 0:
             ts = torch.full((denoised_images.shape[0],), float(ts))
         if noise is None:
-            noise = torch.randn_like(denoised_images)
+            noise = sampler.randn_like(denoised_images)
         a, s = utils.t_to_alpha_sigma(ts.to(self.device))
         return sampler.lincomb2(denoised_images, a, noise, s / 2, (1 - a) / 2)
 
@@ -171,4 +171,4 @@ class VelocityDiffusion(torch.nn.Module):
         add_std = (sr.square() - sf.square() * mult.square()).sqrt()
         diffused_images = diffused_images.to(dev)
         # decode(x*mult + std*noise*k) with x = 2*img-1
-        return sampler.lincomb2(diffused_images, mult, torch.randn_like(diffused_images), add_std * extra_noise_multiplier / 2, (1 - mult) / 2)
+        return sampler.lincomb2(diffused_images, mult, sampler.randn_like(diffused_images), add_std * extra_noise_multiplier / 2, (1 - mult) / 2)

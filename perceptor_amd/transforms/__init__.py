@@ -1,1 +1,2 @@
 from .resize import resize, resize_backward
+from .clamp_with_grad import clamp_with_grad, ClampWithGrad

@@ -54,6 +54,52 @@ def test_predictions_algebra():
     _close(sampling.v_step(img, vg, ft, tt), g["v_guided_step"], 1e-6)
 
 
+def test_predictions_variants_f3():
+    """Oracle restatement of the stochastic / sort / quantile variants and clamp_with_grad vs the reference classes (noise injected)."""
+    g, g2 = golden("sampling"), golden("sampling2")
+    a, s = g["alphas"], g["sigmas"]
+    fi, ti, hi = g["fi"], g["ti"], g2["hi"]
+    img, eps, noise = g["img"], g["eps"], g2["noise"]
+    x0 = sampling.eps_denoised_xs(img, eps, a[fi], s[fi])
+    _close(sampling.step_eta(x0, eps, a[fi], s[fi], a[ti], s[ti], 0.7, noise), g2["eps_step_eta"], 1e-6)
+    _close(sampling.resample_noise(eps, s[fi], s[ti], noise), g2["eps_resample_noise"], 1e-6)
+    _close(sampling.resample(x0, eps, a[fi], s[fi], s[ti], noise), g2["eps_resample"], 1e-6)
+    _close(sampling.noisy_reverse_step(x0, eps, s[fi], a[hi], s[hi], noise), g2["eps_noisy_reverse"], 1e-6)
+    _close(torch.stack([sampling.wasserstein(eps, 1), sampling.wasserstein(eps, 2)]), g2["eps_wasserstein"], 1e-6)
+    ft, tt, ht = g["ft"], g["tt"], g2["ht"]
+    (af, sf), (at, st), (ah, sh) = (sampling.t_to_alpha_sigma(t) for t in (ft, tt, ht))
+    vx0, veps = sampling.v_denoised_xs(img, eps, ft), sampling.v_predicted_noise(img, eps, ft)
+    _close(sampling.step_eta(vx0, veps, af, sf, at, st, 0.7, noise), g2["v_step_eta"], 1e-6)
+    _close(sampling.resample_noise(veps, sf, st, noise), g2["v_resample_noise"], 1e-6)
+    _close(sampling.resample(vx0, veps, af, sf, st, noise), g2["v_resample"], 1e-6)
+    _close(sampling.noisy_reverse_step(vx0, veps, sf, ah, sh, noise), g2["v_noisy_reverse"], 1e-6)
+    _close(torch.stack([sampling.wasserstein(veps, 1), sampling.wasserstein(veps, 2)]), g2["v_wasserstein"], 1e-6)
+    big = g2["big"]
+    _close(torch.stack([sampling.wasserstein(big, 1), sampling.wasserstein(big, 2)]), g2["big_wasserstein"], 1e-6)
+    _close(torch.stack([sampling.quantile_abs(big, q) for q in (0.0, 0.5, 0.95, 0.999, 1.0)]), g2["big_quantiles"], 1e-6)
+    assert torch.equal(sampling.clamp_with_grad_backward(g2["cwg_x"], g2["cwg_g"], 0.0, 1.0), g2["cwg_dx"])
+    assert torch.equal(g2["cwg_x"].clamp(0.0, 1.0), g2["cwg_y"])
+
+
+def test_philox_known_answers_and_randn_contract():
+    """The oracle's Philox4x32-10 against Random123's known-answer vectors; the normal draw is a function of the global element index."""
+    import numpy as np
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = sampling.philox4x32_10(np.array([ctr], dtype=np.uint32), key)[0]
+        assert tuple(int(v) for v in got) == want
+    full = sampling.device_randn((4, 3, 8, 8), seed=99, stream=5)
+    part = sampling.device_randn((2, 3, 8, 8), seed=99, stream=5, first_element=2 * 3 * 8 * 8 - 0)
+    assert torch.equal(full[2:], part)
+    odd = sampling.device_randn((7,), seed=99, stream=5, first_element=3)
+    assert torch.equal(full.flatten()[3:10], odd)
+    z = sampling.device_randn((1 << 16,), seed=1, stream=0)
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.std()) - 1) < 0.02
+    assert not torch.equal(z, sampling.device_randn((1 << 16,), seed=1, stream=1))
+
+
 def test_adm_tiny_fp16_checkpoint_weights():
     """fp32 weights with the torso convolutions cast to fp16 by the reference's own convert_to_fp16() (not bf16-representable)."""
     from conftest import fp16_torso_state_dict
