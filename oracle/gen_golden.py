@@ -244,6 +244,63 @@ def gen_clip():
              grad_sub=g[:, :, ::4, ::4].contiguous(), grad_mom=moments(g))
 
 
+def _hf_vision_tower(cfg, sd, quick_gelu):
+    """transformers' CLIPVisionModelWithProjection built from a config object (no download) and loaded with the open_clip-named
+    synthetic weights ``sd`` -- an INDEPENDENT implementation of the tower open-clip-torch 2.0.2 ships (SURVEY §8c cross-check)."""
+    # the reference loader's torchvision stand-in (oracle/_refimport.py) confuses transformers' optional-dependency probe: hide it
+    hidden = {k: sys.modules.pop(k) for k in [k for k in sys.modules if k == "torchvision" or k.startswith("torchvision.")]}
+    try:
+        from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    finally:
+        sys.modules.update(hidden)
+    res, patch, width, layers, heads, odim = cfg
+    c = CLIPVisionConfig(hidden_size=width, intermediate_size=4 * width, num_hidden_layers=layers, num_attention_heads=heads,
+                         image_size=res, patch_size=patch, projection_dim=odim, hidden_act="quick_gelu" if quick_gelu else "gelu",
+                         layer_norm_eps=1e-5, attention_dropout=0.0)
+    c._attn_implementation = "eager"
+    m = CLIPVisionModelWithProjection(c).eval()
+    hf = {"vision_model.embeddings.class_embedding": sd["class_embedding"],
+          "vision_model.embeddings.patch_embedding.weight": sd["conv1.weight"],
+          "vision_model.embeddings.position_embedding.weight": sd["positional_embedding"],
+          "vision_model.pre_layrnorm.weight": sd["ln_pre.weight"], "vision_model.pre_layrnorm.bias": sd["ln_pre.bias"],
+          "vision_model.post_layernorm.weight": sd["ln_post.weight"], "vision_model.post_layernorm.bias": sd["ln_post.bias"],
+          "visual_projection.weight": sd["proj"].t().contiguous()}
+    for i in range(layers):
+        a, b = f"transformer.resblocks.{i}.", f"vision_model.encoder.layers.{i}."
+        wq, wk, wv = sd[a + "attn.in_proj_weight"].chunk(3, dim=0)
+        bq, bk, bv = sd[a + "attn.in_proj_bias"].chunk(3, dim=0)
+        for nm, w_, b_ in (("q", wq, bq), ("k", wk, bk), ("v", wv, bv)):
+            hf[b + f"self_attn.{nm}_proj.weight"], hf[b + f"self_attn.{nm}_proj.bias"] = w_, b_
+        for src, dst in (("attn.out_proj", "self_attn.out_proj"), ("ln_1", "layer_norm1"), ("ln_2", "layer_norm2"),
+                         ("mlp.c_fc", "mlp.fc1"), ("mlp.c_proj", "mlp.fc2")):
+            hf[b + dst + ".weight"], hf[b + dst + ".bias"] = sd[a + src + ".weight"], sd[a + src + ".bias"]
+    missing, unexpected = m.load_state_dict(hf, strict=False)
+    assert not unexpected and all("position_ids" in k for k in missing), (missing, unexpected)
+    return m
+
+
+def gen_clip_hf():
+    """ViT-L/14 (the benchmarked tower; exact GELU as the laion2b weights use, models/clip.py:21-27) and an exact-GELU tiny tower:
+    resize (the reference's ResizeRight) -> normalise -> transformers CLIP vision tower with the name-keyed synthetic weights."""
+    rz = R.ref("transforms.resize.resize_right")
+    from oracle.clip_vit import CLIP_MEAN, CLIP_STD, VIT_CONFIGS, vit_state_dict_shapes
+    from perceptor_amd.utils.synth import synth_state_dict
+    mean = torch.tensor(CLIP_MEAN)[None, :, None, None]
+    std = torch.tensor(CLIP_STD)[None, :, None, None]
+    for tag, size, n, quick in (("tiny-odd", 40, 2, False), ("ViT-L-14", 256, 1, False), ("ViT-L-14", 256, 1, True)):
+        cfg = VIT_CONFIGS[tag]
+        sd = synth_state_dict(vit_state_dict_shapes(cfg), 0)
+        m = _hf_vision_tower(cfg, sd, quick)
+        img = (seeded_noise((n, 3, size, size), 52) * 0.25 + 0.5).requires_grad_(True)
+        probe = seeded_noise((n, cfg[5]), 53)
+        e = m(pixel_values=(rz.resize(img, out_shape=(cfg[0], cfg[0])) - mean) / std).image_embeds
+        en = torch.nn.functional.normalize(e)
+        (g,) = torch.autograd.grad((en * probe).sum(), img)
+        # the image is seeded_noise((n, 3, size, size), 52) * 0.25 + 0.5: re-derived by the tests, not stored (786 KB at 256x256)
+        save(f"clip_hf_{tag}_{'quickgelu' if quick else 'gelu'}", img_shape=np.array(img.shape), probe=probe, emb=e.detach(), emb_n=en.detach(),
+             grad_sub=g[:, :, ::4, ::4].contiguous(), grad_mom=moments(g))
+
+
 if __name__ == "__main__" and len(sys.argv) > 1:
     for name in sys.argv[1:]:
         globals()["gen_" + name]()

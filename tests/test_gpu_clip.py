@@ -68,6 +68,30 @@ def test_vit_embedding_and_gradient_vs_reference_golden(tag):
     assert torch.allclose(f.norm(dim=1).float(), g["grad_mom"][:, 2], rtol=5e-2)
 
 
+@pytest.mark.parametrize("tag,quick", [("tiny-odd", False), ("ViT-L-14", False), ("ViT-L-14", True)])
+def test_vit_vs_transformers_fixture(tag, quick):
+    """ViT-L/14 (the benchmarked tower, both activations) and an exact-GELU tiny tower against fixtures made with transformers'
+    CLIPVisionModelWithProjection on the same name-keyed weights (oracle/gen_golden.py: gen_clip_hf)."""
+    from perceptor_amd import models
+    from perceptor_amd.utils.synth import seeded_noise
+    g = golden(f"clip_hf_{tag}_{'quickgelu' if quick else 'gelu'}")
+    kw = dict(config=TINY[tag]) if tag in TINY else {}
+    model = models.OpenCLIP(tag, "synthetic", quick_gelu=quick, **kw).to("cuda")
+    img = (seeded_noise(tuple(int(v) for v in g["img_shape"]), 52) * 0.25 + 0.5).cuda().requires_grad_(True)
+    emb = model.encode_images(img, normalize=False)
+    e_rel = _rel(emb.detach().cpu(), g["emb"])
+    with torch.enable_grad():
+        en = model.encode_images(img, normalize=True)
+        (en * g["probe"].cuda()).sum().backward()
+    gr = img.grad.cpu()
+    g_rel = _rel(gr[:, :, ::4, ::4], g["grad_sub"])
+    g_cos = _cos(gr[:, :, ::4, ::4], g["grad_sub"])
+    print(f"[parity] clip(hf) {tag} quick_gelu={quick}: emb rel-L2={e_rel:.3e}, grad rel-L2={g_rel:.3e}, grad cos={g_cos:.5f}")
+    assert e_rel <= 1e-2
+    assert g_rel <= 2e-2 and g_cos >= 0.9995
+    assert torch.allclose(gr.flatten(1).double().norm(dim=1).float(), g["grad_mom"][:, 2], rtol=5e-2)
+
+
 @pytest.mark.parametrize("tag,gelu", [("tiny", False), ("tiny-odd", True), ("tiny-d32", True)])
 def test_loss_and_grad_vs_oracle_and_sharding(tag, gelu):
     from oracle import clip_vit

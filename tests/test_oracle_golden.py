@@ -163,6 +163,23 @@ def test_vit_embedding_and_image_gradient(tag):
     assert float((gr[:, :, ::4, ::4] - g["grad_sub"]).abs().max()) <= 2e-4 * scale
 
 
+@pytest.mark.parametrize("tag,quick", [("tiny-odd", False), ("ViT-L-14", False)])
+def test_vit_vs_transformers_tower(tag, quick):
+    """The oracle's exact-GELU path and the benchmarked ViT-L/14 against an independent implementation: transformers'
+    CLIPVisionModelWithProjection with the same name-keyed weights (oracle/gen_golden.py: gen_clip_hf)."""
+    from perceptor_amd.utils.synth import seeded_noise
+    g = golden(f"clip_hf_{tag}_{'quickgelu' if quick else 'gelu'}")
+    cfg = clip_vit.VIT_CONFIGS[tag]
+    sd = synth_state_dict(clip_vit.vit_state_dict_shapes(cfg), 0)
+    img = (seeded_noise(tuple(int(v) for v in g["img_shape"]), 52) * 0.25 + 0.5).requires_grad_(True)
+    e = clip_vit.encode_images(sd, cfg, img, quick_gelu=quick, normalize=False)
+    _close(e.detach(), g["emb"], 5e-5)
+    en = torch.nn.functional.normalize(e)
+    (gr,) = torch.autograd.grad((en * g["probe"]).sum(), img)
+    scale = float(g["grad_sub"].abs().max())
+    assert float((gr[:, :, ::4, ::4] - g["grad_sub"]).abs().max()) <= 5e-4 * scale
+
+
 def test_spherical_loss_known_values():
     # identical unit vectors -> 0; orthogonal -> 2*asin(sqrt(2)/2)^2 = pi^2/8; antipodal -> pi^2/2
     e = torch.eye(4)[:2]
