@@ -417,8 +417,7 @@ static int g_wd_mf16 = 1;      // pmi_set_option(7, v): its v_mfma_f32_16x16x32 
 void pmi_conv3x3_allow_wd(int v) { g_wd = v; }
 void pmi_conv3x3_wd_mf16(int v) { g_wd_mf16 = v; }
 void pmi_conv3x3_force_config(int cfg) { g_force_cfg = cfg; }
-void pmi_conv3x3_use_glds(int v) { g_prefer0 = v; }      // experiments measured and dropped: direct-to-LDS weights, persistent tiles, start stagger
-void pmi_conv3x3_persistent(int) {}    // incremental patch staging: measured (876 vs 943 TFLOP/s) and dropped
+void pmi_conv3x3_prefer_256(int v) { g_prefer0 = v; }
 
 // Returns the tile config the halo kernel runs for this shape (0: 8x32 px x 256 ch / 8 waves, 1: 16x32 x 128 / 8 waves,
 // 2: 8x32 x 128 / 4 waves x 2 workgroups per CU, 3: 8x32 px x <= 32 channels) or -1 if the shape needs the generic kernel.

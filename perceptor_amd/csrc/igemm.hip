@@ -550,8 +550,7 @@ int pmi_gemm_wd_launch(const pmi_igemm_args* a, void* stream);
 void pmi_conv3x3_allow_wd(int v);
 void pmi_conv3x3_wd_mf16(int v);
 void pmi_conv3x3_force_config(int cfg);
-void pmi_conv3x3_use_glds(int v);
-void pmi_conv3x3_persistent(int v);
+void pmi_conv3x3_prefer_256(int v);
 static int g_allow_halo = 1;
 // Split-K factor the generic kernel wants for this shape (1 = none): small-M layers (16x16 / 8x8 feature maps) otherwise
 // launch far fewer workgroups than the 256 CUs.  The caller then provides ws = S * M * N floats.
@@ -592,8 +591,7 @@ extern "C" int pmi_igemm_stats_rows(const pmi_igemm_args* a) {
 extern "C" int pmi_set_option(int key, int value) {
   if (key == 0) { const int old = g_allow_halo; g_allow_halo = value; return old; }
   if (key == 1) { pmi_conv3x3_force_config(value); return 0; }
-  if (key == 2) { pmi_conv3x3_use_glds(value); return 0; }
-  if (key == 3) { pmi_conv3x3_persistent(value); return 0; }
+  if (key == 2) { pmi_conv3x3_prefer_256(value); return 0; }
   if (key == 6) { pmi_conv3x3_allow_wd(value); return 0; }
   if (key == 7) { pmi_conv3x3_wd_mf16(value); return 0; }
   return PMI_ERR_ARG;

@@ -11,7 +11,7 @@ p.add_argument("--n", type=int, default=8); p.add_argument("--hw", type=int, def
 p.add_argument("--cin", type=int, default=256); p.add_argument("--cout", type=int, default=256)
 p.add_argument("--iters", type=int, default=20); p.add_argument("--dtype", default="bf16")
 p.add_argument("--halo", type=int, default=1); p.add_argument("--pro", type=int, default=0)
-p.add_argument("--rounds", type=int, default=3); p.add_argument("--cfg", type=int, default=-1); p.add_argument("--glds", type=int, default=1); p.add_argument("--dbg", type=int, default=0); p.add_argument("--persist", type=int, default=1); p.add_argument("--stamps", type=int, default=0); p.add_argument("--res", type=int, default=0); p.add_argument("--stats", type=int, default=0)
+p.add_argument("--rounds", type=int, default=3); p.add_argument("--cfg", type=int, default=-1); p.add_argument("--dbg", type=int, default=0); p.add_argument("--stamps", type=int, default=0); p.add_argument("--res", type=int, default=0); p.add_argument("--stats", type=int, default=0)
 a = p.parse_args()
 dev = torch.device("cuda:0")
 dt = dtype_code(a.dtype)
@@ -26,8 +26,6 @@ if a.pro:
 flops = 2.0 * a.n * a.hw * a.hw * a.cin * a.cout * 9
 from perceptor_amd import _hip
 _hip.lib().pmi_set_option(1, a.cfg)
-_hip.lib().pmi_set_option(2, a.glds)
-_hip.lib().pmi_set_option(3, a.persist)
 STAMP = None
 for halo in ([a.halo] if a.halo in (0, 1) else [0, 1]):
     ops.set_halo(bool(halo))
@@ -41,7 +39,7 @@ for halo in ([a.halo] if a.halo in (0, 1) else [0, 1]):
             ops.igemm(x, lin, prologue=pro, out=out, residual=res, want_stats=bool(a.stats))
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / a.iters
-        print(f"halo={halo} cfg={a.cfg} glds={a.glds} dbg={a.dbg} persist={a.persist} n={a.n} hw={a.hw} cin={a.cin} cout={a.cout} pro={a.pro}: {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s", flush=True)
+        print(f"halo={halo} cfg={a.cfg} dbg={a.dbg} n={a.n} hw={a.hw} cin={a.cin} cout={a.cout} pro={a.pro}: {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s", flush=True)
 
 if a.stamps:
     # needs conv3x3.hip built with -DPMI_STAMPS: per-workgroup wall_clock64 (100 MHz) at entry / first barrier / main loop end /
