@@ -1,5 +1,6 @@
 // Shared device helpers for the gfx950 (CDNA4) kernels.  wave = 64 lanes.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -147,6 +148,29 @@ __device__ __forceinline__ float act_apply(float x, int act) {
     case PMI_ACT_QUICKGELU: return x * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * x));
     default: return x;
   }
+}
+
+// Runs f(std::integral_constant<int, ACT>) for the runtime activation code, so an epilogue's element loops are compiled once per
+// activation with act_apply's switch folded away (called per element with a runtime code, the switch is a chain of scalar branches per
+// value: ~4 us of a 60 us convolution tile).
+template <typename F>
+__device__ __forceinline__ void act_switch(int act, F&& f) {
+  switch (act) {
+    case PMI_ACT_RELU: f(std::integral_constant<int, PMI_ACT_RELU>()); break;
+    case PMI_ACT_SILU: f(std::integral_constant<int, PMI_ACT_SILU>()); break;
+    case PMI_ACT_GELU: f(std::integral_constant<int, PMI_ACT_GELU>()); break;
+    case PMI_ACT_QUICKGELU: f(std::integral_constant<int, PMI_ACT_QUICKGELU>()); break;
+    default: f(std::integral_constant<int, PMI_ACT_NONE>()); break;
+  }
+}
+
+// act over a short vector with ONE dispatch on the runtime code
+template <int N>
+__device__ __forceinline__ void act_apply_n(float* v, int act) {
+  act_switch(act, [&](auto act_c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < N; ++e) v[e] = act_apply(v[e], decltype(act_c)::value);
+  });
 }
 
 // d act(x) / dx

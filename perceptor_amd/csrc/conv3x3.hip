@@ -284,20 +284,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv3x3_halo_kernel(const pmi
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int j = pass * 2 + jj;
+      float4 bb[4];                                          // read before the staging writes (same LDS: the compiler cannot hoist them)
 #pragma unroll
-      for (int i = 0; i < XB; ++i)
+      for (int g = 0; g < 4; ++g) bb[g] = *(const float4*)(bsm + wn * 128 + j * 32 + 4 * lhi + 8 * g);
+      act_switch(a.act, [&](auto act_c) __attribute__((always_inline)) {     // element loop compiled per activation
+        constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int cl = wn * 128 + j * 32 + 4 * lhi + 8 * g;
-          const float4 b = *(const float4*)(bsm + cl);
-          float v[4] = {acc[i][j][4 * g] * a.alpha + b.x, acc[i][j][4 * g + 1] * a.alpha + b.y,
-                        acc[i][j][4 * g + 2] * a.alpha + b.z, acc[i][j][4 * g + 3] * a.alpha + b.w};
-          if (a.act != PMI_ACT_NONE) {
+        for (int i = 0; i < XB; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
+          for (int g = 0; g < 4; ++g) {
+            const float4 b = bb[g];
+            float v[4] = {acc[i][j][4 * g] * a.alpha + b.x, acc[i][j][4 * g + 1] * a.alpha + b.y,
+                          acc[i][j][4 * g + 2] * a.alpha + b.z, acc[i][j][4 * g + 3] * a.alpha + b.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], ACT);
+            *(uint2*)(stg + (i * 32 + l31) * SROW + (jj * 32 + 4 * lhi + 8 * g) * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
           }
-          *(uint2*)(stg + (i * 32 + l31) * SROW + (jj * 32 + 4 * lhi + 8 * g) * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
-        }
+      });
     }
     const int cl0 = wn * 128 + pass * 64 + r8 * 8;           // this lane's 8 channels inside the tile
     const bool nok = n0 + cl0 < a.N;

@@ -303,39 +303,45 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wd_kernel(const pmi_igemm_args
     }
   }
   __syncthreads();                                     // bsm visible (the main loop's last barrier already freed the patch buffers)
-  if constexpr (MF16) {
+  // bias values of this lane's columns, read once (a read between the staging writes cannot be hoisted by the compiler: same LDS)
+  act_switch(a.act, [&](auto act_c) __attribute__((always_inline)) {
+    constexpr int ACT = decltype(act_c)::value;
+    if constexpr (MF16) {
+      float4 bb[2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+      for (int cb = 0; cb < 2; ++cb) bb[cb] = *(const float4*)(bsm + wn * 32 + cb * 16 + 4 * (lane >> 4));
 #pragma unroll
-      for (int sx = 0; sx < 2; ++sx)
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-          const int cl = wn * 32 + cb * 16 + 4 * (lane >> 4);
-          const float4 b = *(const float4*)(bsm + cl);
-          const f32x4 c = acc4[i][sx][cb];
-          float v[4] = {c[0] * a.alpha + b.x, c[1] * a.alpha + b.y, c[2] * a.alpha + b.z, c[3] * a.alpha + b.w};
-          if (a.act != PMI_ACT_NONE) {
+        for (int sx = 0; sx < 2; ++sx)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
+          for (int cb = 0; cb < 2; ++cb) {
+            const int cl = wn * 32 + cb * 16 + 4 * (lane >> 4);
+            const float4 b = bb[cb];
+            const f32x4 c = acc4[i][sx][cb];
+            float v[4] = {c[0] * a.alpha + b.x, c[1] * a.alpha + b.y, c[2] * a.alpha + b.z, c[3] * a.alpha + b.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], ACT);
+            *(uint2*)(stg + (i * 32 + sx * 16 + (lane & 15)) * SROW + cl * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
           }
-          *(uint2*)(stg + (i * 32 + sx * 16 + (lane & 15)) * SROW + cl * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
+    } else {
+      float4 bb[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bb[g] = *(const float4*)(bsm + wn * 32 + 8 * g + 4 * lhi);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int cl = wn * 32 + 8 * g + 4 * lhi;
+          const float4 b = bb[g];
+          float v[4] = {acc[i][4 * g] * a.alpha + b.x, acc[i][4 * g + 1] * a.alpha + b.y,
+                        acc[i][4 * g + 2] * a.alpha + b.z, acc[i][4 * g + 3] * a.alpha + b.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], ACT);
+          *(uint2*)(stg + (i * 32 + l31) * SROW + cl * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
         }
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int cl = wn * 32 + 8 * g + 4 * lhi;
-        const float4 b = *(const float4*)(bsm + cl);
-        float v[4] = {acc[i][4 * g] * a.alpha + b.x, acc[i][4 * g + 1] * a.alpha + b.y,
-                      acc[i][4 * g + 2] * a.alpha + b.z, acc[i][4 * g + 3] * a.alpha + b.w};
-        if (a.act != PMI_ACT_NONE) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
-        }
-        *(uint2*)(stg + (i * 32 + l31) * SROW + cl * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
-      }
-  }
+    }
+  });
   __syncthreads();
   STAMP(6);
   float cs[16];                                        // [0..7] sums, [8..15] sums of squares of this lane's 8 channels

@@ -140,24 +140,27 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
     // written out as 512-byte rows, 16 bytes per lane; a 16-bit residual is added on the way out ----
     constexpr int HROW = 256 * 2 + 16;
     static_assert(2 * TM * HROW <= 160 * 1024, "the two 16-bit epilogue images (output, pre-activation) must fit the LDS");
+    act_switch(a.act, [&](auto act_c) __attribute__((always_inline)) {    // element loops compiled per activation (no per-value switch)
+      constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      const int nl = wid * 32 + cb * 16 + 4 * (lane >> 4);
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a.bias) bv = *(const float4*)(a.bias + n0 + nl);
+      for (int cb = 0; cb < 2; ++cb) {
+        const int nl = wid * 32 + cb * 16 + 4 * (lane >> 4);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) bv = *(const float4*)(a.bias + n0 + nl);
 #pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const f32x4 c = acc[mb][cb];
-        float v[4] = {c[0] * a.alpha + bv.x, c[1] * a.alpha + bv.y, c[2] * a.alpha + bv.z, c[3] * a.alpha + bv.w};
-        if (a.D2) *(uint2*)(smem + TM * HROW + (mb * 16 + (lane & 15)) * HROW + nl * 2) = pack4<T>(v[0], v[1], v[2], v[3]);   // pre-activation image
-        if (a.act != PMI_ACT_NONE) {
+        for (int mb = 0; mb < MB; ++mb) {
+          const f32x4 c = acc[mb][cb];
+          float v[4] = {c[0] * a.alpha + bv.x, c[1] * a.alpha + bv.y, c[2] * a.alpha + bv.z, c[3] * a.alpha + bv.w};
+          if (ACT != PMI_ACT_NONE && a.D2)
+            *(uint2*)(smem + TM * HROW + (mb * 16 + (lane & 15)) * HROW + nl * 2) = pack4<T>(v[0], v[1], v[2], v[3]);   // pre-activation image
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
+          for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], ACT);
+          *(uint2*)(smem + (mb * 16 + (lane & 15)) * HROW + nl * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
         }
-        *(uint2*)(smem + (mb * 16 + (lane & 15)) * HROW + nl * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
       }
-    }
+    });
     __syncthreads();
+    const bool d2_img = a.D2 && a.act != PMI_ACT_NONE;   // without an activation the second output equals the first
     const int pc8 = tid & 31, prow = tid >> 5;         // 8 columns (16 B) x rows prow + 16 j
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
@@ -169,8 +172,19 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
         unpack8<T>(v, f);
         if (a.aux) {
           unpack8<T>(*(const uint4*)((const u16*)a.aux + (int64_t)m * a.ldd + n0 + pc8 * 8), rr);
+          switch (a.aux_act) {                            // the activation code is folded per case (no per-value switch)
+            case PMI_ACT_GELU:
 #pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] *= act_grad(rr[e], a.aux_act);
+              for (int e = 0; e < 8; ++e) f[e] *= act_grad(rr[e], PMI_ACT_GELU);
+              break;
+            case PMI_ACT_QUICKGELU:
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] *= act_grad(rr[e], PMI_ACT_QUICKGELU);
+              break;
+            default:
+#pragma unroll
+              for (int e = 0; e < 8; ++e) f[e] *= act_grad(rr[e], a.aux_act);
+          }
         }
         if (a.R) {
           unpack8<T>(*(const uint4*)((const u16*)a.R + (int64_t)m * a.ldr + n0 + pc8 * 8), rr);
@@ -180,7 +194,10 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
         v = pack8<T>(f);
       }
       *(uint4*)((u16*)a.D + (int64_t)m * a.ldd + n0 + pc8 * 8) = v;
-      if (a.D2) *(uint4*)((u16*)a.D2 + (int64_t)m * a.ldd + n0 + pc8 * 8) = *(const uint4*)(smem + TM * HROW + r * HROW + pc8 * 16);
+      if (a.D2) {
+        const uint4 v2 = *(const uint4*)(smem + (d2_img ? TM * HROW : 0) + r * HROW + pc8 * 16);
+        *(uint4*)((u16*)a.D2 + (int64_t)m * a.ldd + n0 + pc8 * 8) = v2;
+      }
     }
     GSTAMP(3);
     return;
@@ -188,6 +205,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
   // ---- epilogue, fp32 output / fp32 residual / split-K slabs: straight from the accumulators -- a lane holds 4 consecutive columns
   // (16 bytes fp32) of one row, the four quarter-waves of a block complete 64-byte runs, the two blocks of a wave a 128-byte line ----
   float* const Dslab = raw ? (float*)a.ws + (int64_t)blockIdx.z * a.M * a.N : nullptr;
+  act_switch(raw ? PMI_ACT_NONE : a.act, [&](auto act_c) __attribute__((always_inline)) {
+  constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int n = n0 + wid * 32 + cb * 16 + 4 * (lane >> 4);
@@ -203,10 +222,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
         continue;
       }
       float v[4] = {c[0] * a.alpha + bv.x, c[1] * a.alpha + bv.y, c[2] * a.alpha + bv.z, c[3] * a.alpha + bv.w};
-      if (a.act != PMI_ACT_NONE) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
-      }
+      for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], ACT);
       if (a.R) {
         if (a.res_f32) {
           const float4 rr = *(const float4*)((const float*)a.R + (int64_t)m * a.ldr + n);
@@ -221,6 +238,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
       else *(uint2*)((u16*)a.D + (int64_t)m * a.ldd + n) = pack4<T>(v[0], v[1], v[2], v[3]);
     }
   }
+  });
   GSTAMP(3);
 }
 

@@ -278,10 +278,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
           float v[4] = {acc[i][j][4 * g] * a.alpha + b.x, acc[i][j][4 * g + 1] * a.alpha + b.y,
                         acc[i][j][4 * g + 2] * a.alpha + b.z, acc[i][j][4 * g + 3] * a.alpha + b.w};
           if (nbq[i] && n < a.N) { const float4 q = *(const float4*)(nbq[i] + n); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
-          if (a.act != PMI_ACT_NONE) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
-          }
+          if (a.act != PMI_ACT_NONE) act_apply_n<4>(v, a.act);
           *(uint2*)(stg + (i * 32 + l31) * SROW + (j * 32 + 8 * g + 4 * lhi) * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
         }
       }
@@ -404,10 +401,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const pmi_igemm_args a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * a.alpha;
         v[0] += bv[g].x + nbv[i][g].x; v[1] += bv[g].y + nbv[i][g].y; v[2] += bv[g].z + nbv[i][g].z; v[3] += bv[g].w + nbv[i][g].w;
-        if (a.act != PMI_ACT_NONE) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
-        }
+        if (a.act != PMI_ACT_NONE) act_apply_n<4>(v, a.act);
         if (a.R) {
           if (a.res_f32) {
             v[0] += rv[i][g].x; v[1] += rv[i][g].y; v[2] += rv[i][g].z; v[3] += rv[i][g].w;
@@ -473,10 +467,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const pmi_igemm_args
       const float4 b = *(const float4*)(a.nbias + (int64_t)(m / a.hw) * (a.ldnb ? a.ldnb : a.N) + n);
       v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
     }
-    if (a.act != PMI_ACT_NONE) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], a.act);
-    }
+    if (a.act != PMI_ACT_NONE) act_apply_n<4>(v, a.act);
     if (a.R) {
       int64_t rrow = (int64_t)m * a.ldr;
       if (a.res_up) {
