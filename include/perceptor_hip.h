@@ -204,6 +204,20 @@ int pmi_sort_rows(const float* x, float* work, int rows, int64_t n, pmi_stream_t
 int pmi_wasserstein(const float* sorted, int rows, int64_t n, int power, float* partial, float* out, pmi_stream_t s);
 int pmi_clamp_grad(const float* x, const float* grad, const float* lo, const float* hi, float* out, int N, int64_t chw, pmi_stream_t s);
 
+/* ---- input-gradient of the v-diffusion UNets (csrc/backward.hip) --------------------------------------------
+ * What autograd computes upstream when losses/velocity_diffusion.py:33-61 (guided_resample_) backpropagates a loss on the denoised
+ * image to the noise.  dX of every convolution is pmi_igemm on flipped / transposed packed weights and the attention backward is
+ * pmi_vit_attn_bwd; these are the memory-bound adjoints between them (16-bit NHWC, dtype 0 / 1):
+ * pmi_add16: out = a + b (ResConvBlock main + skip, yfcc_2.py:17-28, when the ReLU output must survive for its mask);
+ * pmi_avgpool2_bwd: dy [N][H/2][W/2][C] -> dx [N][H][W][C] (nn.AvgPool2d(2)); pmi_upsample_bilinear2_bwd: dy [N][2H][2W][C] -> dx
+ * [N][H][W][C] (exact adjoint of pmi_upsample_bilinear2); pmi_gn1_bwd: GroupNorm(1, C) with affine, dx = r (g - mean g - xhat mean(g xhat))
+ * (+ res), g = gamma dy, one workgroup per sample, fixed-order reduction (SelfAttention2d.norm, yfcc_2.py:41-52).                       */
+int pmi_add16(const void* a, const void* b, void* out, int64_t n, int dtype, pmi_stream_t s);
+int pmi_avgpool2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, pmi_stream_t s);
+int pmi_upsample_bilinear2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, pmi_stream_t s);
+int pmi_gn1_bwd(const void* x, const void* dy, const float* gamma, const void* res, void* dx, int N, int64_t hw, int C, float eps,
+                int dtype, pmi_stream_t s);
+
 /* ---- CLIP guidance path (forward + input-gradient) ---------------------------------------
  * ViT arithmetic: open-clip-torch 2.0.2 visual tower == OpenAI-CLIP VisionTransformer, in-tree copy
  * ruclip/model.py:11-131; wrapper models/open_clip.py:109-123; loss losses/clip/clip.py:89-99.

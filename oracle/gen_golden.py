@@ -204,6 +204,22 @@ def gen_vdiff():
     save("vdiff_cc12m_1_64", x=x, t=t, clip_embed=ce, y_sub=y[:, :, ::2, ::2].contiguous(), y_mom=moments(y))
 
 
+def gen_vdiff_grad():
+    """Row f2: the input gradient autograd computes through the reference's YFCC2Model (what guided_resample_ backpropagates,
+    losses/velocity_diffusion.py:33-61): d sum(probe * v) / d x at 128x128, full 968 M-parameter net, name-keyed weights."""
+    y2 = R.ref("models.velocity_diffusion.yfcc_2")
+    m = y2.YFCC2Model().eval()
+    m.load_state_dict(synth_like(m.state_dict(), 0))
+    for p_ in m.parameters():
+        p_.requires_grad_(False)
+    x = seeded_noise((1, 3, 128, 128), 41).requires_grad_(True)
+    t = torch.tensor([0.3])
+    probe = seeded_noise((1, 3, 128, 128), 46)
+    v = m(x, t)
+    (g,) = torch.autograd.grad((v * probe).sum(), x)
+    save("vdiff_yfcc_2_128_grad", t=t, g_sub=g[:, :, ::2, ::2].contiguous(), g_mom=moments(g), v_mom=moments(v.detach()))
+
+
 def gen_vdiff2():
     y1 = R.ref("models.velocity_diffusion.yfcc_1")
     wa = R.ref("models.velocity_diffusion.wikiart_256")

@@ -97,6 +97,11 @@ _PROTOS = {
     "pmi_sort_rows": ([_P, _P, _I, _L, _P],),
     "pmi_wasserstein": ([_P, _I, _L, _I, _P, _P, _P],),
     "pmi_clamp_grad": ([_P, _P, _P, _P, _P, _I, _L, _P],),
+    # UNet input-gradient adjoints (backward.hip)
+    "pmi_add16": ([_P, _P, _P, _L, _I, _P],),
+    "pmi_avgpool2_bwd": ([_P, _P, _I, _I, _I, _I, _I, _P],),
+    "pmi_upsample_bilinear2_bwd": ([_P, _P, _I, _I, _I, _I, _I, _P],),
+    "pmi_gn1_bwd": ([_P, _P, _P, _P, _P, _I, _L, _I, _F, _I, _P],),
     # CLIP path (clip.hip)
     "pmi_layernorm_fwd": ([_P, _I, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],),
     "pmi_layernorm_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],),

@@ -306,3 +306,205 @@ class VDiffEngine:
         out = torch.empty((n, 3, hh, ww), dtype=torch.float32, device=dev)
         call("pmi_finish_output", ptr(y), y.shape[-1], ptr(out), n, hh, ww, 3)
         return out
+
+    # ---- input gradient -----------------------------------------------------------------------------------
+    # What autograd gives the reference when losses/velocity_diffusion.py:33-61 (guided_resample_) backpropagates a loss on the
+    # denoised image to the noise: d loss / d images through the UNet, weights frozen.  forward_train() runs the same kernels as
+    # forward() but keeps, per block, the tensors a backward needs (the post-ReLU outputs double as ReLU masks); backward() walks the
+    # tape in reverse.  dX of a convolution is the forward convolution on transposed + flipped weights (packed lazily, once), so the
+    # MFMA kernels, their fused residual add and the fragment-ordered weight paths are reused unchanged.
+    def _check_backward_support(self):
+        if self.cond:
+            raise NotImplementedError("input gradient: the CLIP-conditioned nets (Modulation2d blocks, cc12m_1) are not built yet")
+        if self.precise:
+            raise NotImplementedError("input gradient runs in the 16-bit modes (bf16 / f16)")
+        if self.spec.get("head_dim", 64) != 64 or not self.spec.get("attn_norm", True) or self.spec.get("up_mode", "bilinear") != "bilinear":
+            raise NotImplementedError("input gradient: only the yfcc_2 / yfcc_1 layer set (64-channel heads, GroupNorm(1) attention, "
+                                      "bilinear upsampling) is built")
+
+    def _wt(self, key, weight, cin_pad=None):
+        """Packed weights of the input-gradient convolution of `weight` [Cout, Cin, k, k]: [Cin, Cout, k, k] with both taps flipped."""
+        if key not in self.w:
+            w = weight.detach().float().permute(1, 0, 2, 3)
+            if w.shape[-1] == 3:
+                w = w.flip(2, 3)
+            self.w[key] = PackedLinear(w.contiguous(), None, self.dt, self.device, cin_pad=cin_pad)
+        return self.w[key]
+
+    def _res_train(self, l: Res, p, x, x1, tape):
+        dt, w = self.dt, self.w
+        h1 = ops.igemm(x, w[p + ".c1"], a1=x1, act=ACT_RELU)
+        if l.last:
+            skip = ops.igemm(x, w[p + ".skip"], a1=x1)
+            y = ops.igemm(h1, w[p + ".c2"], residual=skip, out_f32=True)
+            r2 = None
+        else:
+            r2 = ops.igemm(h1, w[p + ".c2"], act=ACT_RELU)                      # kept apart from the skip path: its sign is the ReLU mask
+            if l.cin != l.cout:
+                y = ops.igemm(x, w[p + ".skip"], a1=x1, residual=r2)
+            else:
+                y = torch.empty_like(r2)
+                call("pmi_add16", ptr(r2), ptr(x), ptr(y), r2.numel(), dt)
+        tape.append(("res", l, p, h1, r2, x1 is not None))
+        return y
+
+    def _attn_train(self, l: Attn, p, x, tape):
+        dt, w = self.dt, self.w
+        n, hh, ww, c = x.shape
+        t, heads = hh * ww, c // 64
+        g, b = w[p + ".gn"]
+        hn = ops.group_norm(x, g, b, 1, dt)
+        qkv = ops.igemm(hn.view(n * t, c), w[p + ".qkv"])
+        tp32 = (t + 31) // 32 * 32
+        aws = torch.empty((6, n * heads, tp32, 64), dtype=x.dtype, device=x.device)
+        lse = torch.empty((n * heads, tp32), dtype=torch.float32, device=x.device)
+        a = torch.empty((n * t, c), dtype=x.dtype, device=x.device)
+        call("pmi_vit_attn_fwd", ptr(qkv), ptr(aws), ptr(lse), ptr(a), n, t, heads, 64.0 ** -0.5, dt)
+        y = ops.igemm(a, w[p + ".out"], residual=x.view(n * t, c)).view(n, hh, ww, c)
+        tape.append(("attn", l, p, x, aws, lse, a))
+        return y
+
+    def _run_train(self, prog, prefix, x, tape):
+        x1 = None
+        for i, l in enumerate(prog):
+            p = f"{prefix}.{i}"
+            if isinstance(l, Res):
+                x, x1 = self._res_train(l, p, x, x1, tape), None
+            elif isinstance(l, Attn):
+                x = self._attn_train(l, p, x, tape)
+            elif isinstance(l, Down):
+                x = ops.avgpool2(x, self.dt)
+                tape.append(("down",))
+            elif isinstance(l, Up):
+                x = ops.upsample_bilinear2(x, self.dt)
+                tape.append(("up",))
+            elif isinstance(l, Skip):
+                inner_tape = []
+                inner = self._run_train(l.main, p + ".main", x, inner_tape)
+                tape.append(("skip", inner_tape))
+                x, x1 = inner, x                       # torch.cat([main(x), x], dim=1)   (yfcc_2.py:31-38)
+        assert x1 is None
+        return x
+
+    @torch.no_grad()
+    def forward_train(self, images: torch.Tensor, t: torch.Tensor):
+        """As forward(), keeping what backward() needs.  Returns (v NCHW fp32, tape)."""
+        self._check_backward_support()
+        if not images.is_cuda:
+            raise RuntimeError("VDiffEngine runs on a HIP device only (no CPU fallback)")
+        dt, dev = self.dt, self.device
+        images = images.float().contiguous()
+        n, _, hh, ww = images.shape
+        t = t.to(device=dev, dtype=torch.float32).contiguous()
+        planes = torch.empty((n, 16), dtype=torch.float32, device=dev)
+        call("pmi_fourier_features", ptr(t), ptr(self.tw), ptr(planes), n, 8)
+        x = torch.empty((n, hh, ww, 24), dtype=_hip.TORCH_DTYPE[dt], device=dev)
+        call("pmi_prep_input", ptr(images), ptr(planes), 16, ptr(x), n, hh, ww, 24, dt)
+        tape = []
+        y = self._run_train(self.spec["net"], "net", x, tape)
+        out = torch.empty((n, 3, hh, ww), dtype=torch.float32, device=dev)
+        call("pmi_finish_output", ptr(y), y.shape[-1], ptr(out), n, hh, ww, 3)
+        return out, tape
+
+    def _mask(self, g, y):
+        """g * (y > 0) in place: y is a post-ReLU tensor, its sign is the mask."""
+        call("pmi_act_bwd", ptr(g), ptr(y), ptr(g), g.numel(), ACT_RELU, self.dt)
+        return g
+
+    def _res_back(self, rec, g, sd, first):
+        _, l, p, h1, r2, two = rec
+        j = 2
+        w2 = sd[p + f".main.{j}.weight"]
+        w1 = sd[p + ".main.0.weight"]
+        if l.last:
+            d2 = g                                                               # [N,H,W,8]: 3 channels + padding
+            c2t = self._wt(p + ".c2T", w2, cin_pad=8)
+        else:
+            d2 = self._mask(g.clone(), r2)
+            c2t = self._wt(p + ".c2T", w2)
+        dh1 = self._mask(ops.igemm(d2, c2t), h1)
+        has_skip = l.cin != l.cout
+        skw = sd[p + ".skip.weight"] if has_skip else None
+        spad = 8 if l.last else None
+        if not two:
+            gs = ops.igemm(g, self._wt(p + ".skipT", skw, cin_pad=spad)) if has_skip else g
+            return ops.igemm(dh1, self._wt(p + ".c1T", w1), residual=gs, out_f32=first), None
+        half = l.cin // 2                                                        # conv1 / skip read cat([main(x), x]): one dX per source
+        outs = []
+        for k in range(2):
+            sl = slice(k * half, (k + 1) * half)
+            gs = ops.igemm(g, self._wt(p + f".skipT{k}", skw[:, sl], cin_pad=spad))
+            outs.append(ops.igemm(dh1, self._wt(p + f".c1T{k}", w1[:, sl]), residual=gs))
+        return outs[0], outs[1]
+
+    def _attn_back(self, rec, g, sd):
+        _, l, p, x, aws, lse, a = rec
+        dt = self.dt
+        n, hh, ww, c = x.shape
+        t, heads = hh * ww, c // 64
+        g2 = g.reshape(n * t, c)
+        da = ops.igemm(g2, self._wt(p + ".outT", sd[p + ".out_proj.weight"]))
+        tp32 = (t + 31) // 32 * 32
+        bws = torch.empty((2, n * heads, tp32, 64), dtype=x.dtype, device=x.device)
+        delta = torch.empty((n * heads, tp32), dtype=torch.float32, device=x.device)
+        dqkv = torch.empty((n * t, 3 * c), dtype=x.dtype, device=x.device)
+        call("pmi_vit_attn_bwd", ptr(aws), ptr(lse), ptr(a), ptr(da), ptr(bws), ptr(delta), ptr(dqkv), n, t, heads, 64.0 ** -0.5, dt)
+        dhn = ops.igemm(dqkv, self._wt(p + ".qkvT", sd[p + ".qkv_proj.weight"]))
+        gx = torch.empty_like(x)
+        call("pmi_gn1_bwd", ptr(x), ptr(dhn), ptr(self.w[p + ".gn"][0]), ptr(g2), ptr(gx), n, t, c, 1e-5, dt)
+        return gx
+
+    def _back(self, tape, g, sd, outermost=False):
+        """Gradient wrt the input of the block sequence recorded in `tape`, given g = gradient wrt its output."""
+        g1 = None
+        for idx in range(len(tape) - 1, -1, -1):
+            rec = tape[idx]
+            kind = rec[0]
+            if kind == "res":
+                assert g1 is None
+                g, g1 = self._res_back(rec, g, sd, first=outermost and idx == 0)
+            elif kind == "skip":
+                assert g1 is not None, "a SkipBlock is always followed by the block that reads its concat"
+                gm = self._back(rec[1], g, sd)                                   # through main(x)
+                out = torch.empty_like(gm)
+                call("pmi_add16", ptr(gm), ptr(g1), ptr(out), gm.numel(), self.dt)
+                g, g1 = out, None
+            else:
+                assert g1 is None
+                if kind == "attn":
+                    g = self._attn_back(rec, g, sd)
+                elif kind == "down":
+                    n, h, w_, c = g.shape
+                    out = torch.empty((n, 2 * h, 2 * w_, c), dtype=g.dtype, device=g.device)
+                    call("pmi_avgpool2_bwd", ptr(g), ptr(out), n, 2 * h, 2 * w_, c, self.dt)
+                    g = out
+                elif kind == "up":
+                    n, h, w_, c = g.shape
+                    out = torch.empty((n, h // 2, w_ // 2, c), dtype=g.dtype, device=g.device)
+                    call("pmi_upsample_bilinear2_bwd", ptr(g), ptr(out), n, h // 2, w_ // 2, c, self.dt)
+                    g = out
+        assert g1 is None
+        return g
+
+    @torch.no_grad()
+    def backward(self, tape, d_v: torch.Tensor, state_dict) -> torch.Tensor:
+        """d loss / d images (NCHW fp32, images in [0, 1]) from d loss / d v (NCHW fp32 [N, 3, H, W]) and the tape of forward_train().
+        `state_dict`: the model's parameters (reference key names) -- the transposed weight packings are built from it on first use.
+        f16 engines scale the gradient by a power of two (largest incoming value -> 1) on the way in and back on the way out: image
+        gradients of a CLIP loss are ~1e-6 and would flush to zero in f16; bf16 needs no scaling."""
+        self._check_backward_support()
+        dev, dt = self.device, self.dt
+        n, _, hh, ww = d_v.shape
+        scale = 1.0
+        if dt == _hip.DT_F16:                         # keep the f16 gradient tensors in range: largest incoming value -> 1 (power of two: exact)
+            amax = float(d_v.abs().max())
+            if amax > 0.0 and amax == amax:
+                scale = 2.0 ** max(-24, min(24, -int(torch.tensor(amax).log2().ceil())))
+        g = torch.zeros((n, hh, ww, 8), dtype=_hip.TORCH_DTYPE[dt], device=dev)                # 3 channels + padding (layout only)
+        g[..., :3] = (d_v.to(dev).float() * scale).permute(0, 2, 3, 1)
+        sd = {k: v.detach() for k, v in state_dict.items()}
+        gx = self._back(tape, g, sd, outermost=True)                                            # fp32 [N,H,W,20]: d / d (x, Fourier planes)
+        out = torch.empty((n, 3, hh, ww), dtype=torch.float32, device=dev)
+        call("pmi_finish_output", ptr(gx), gx.shape[-1], ptr(out), n, hh, ww, 3)
+        return out * (2.0 / scale)                                                              # x = 2 * images - 1
+

@@ -18,6 +18,22 @@ _SPECS = {"yfcc_2": vdiff.yfcc2_spec, "yfcc_1": vdiff.yfcc1_spec, "cc12m_1": vdi
 _LATER = ()
 
 
+class _Velocities(torch.autograd.Function):
+    """velocities(x, t) with an input gradient, as autograd provides upstream (the UNet is an nn.Module there): forward and backward
+    are the HIP engine's forward_train / backward (engine/vdiff.py).  Weights are frozen: no parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, diffused, t, model):
+        v, tape = model.engine.forward_train(diffused, t)
+        ctx.model, ctx.tape = model, tape
+        return v
+
+    @staticmethod
+    def backward(ctx, grad_v):
+        m = ctx.model
+        return m.engine.backward(ctx.tape, grad_v.contiguous(), m.model.state_dict()), None, None
+
+
 class VelocityDiffusion(torch.nn.Module):
     def __init__(self, name="yfcc_2", *, weights="synthetic", checkpoint: Optional[str] = None, dtype="bf16", seed=0, spec=None,
                  weight_gain: float = 1.0):
@@ -124,6 +140,8 @@ class VelocityDiffusion(torch.nn.Module):
             t = torch.full((diffused.shape[0],), float(t))
         elif t.ndim == 0:          # same value as the reference's float(t), without a device->host sync (HIP-graph capturable)
             t = t.reshape(1).expand(diffused.shape[0])
+        if torch.is_grad_enabled() and diffused.requires_grad:          # autograd through the UNet (guided_resample_-style scripts)
+            return _Velocities.apply(diffused, t.to(self.device), self)
         ce = conditioning.squeeze(dim=1) if (self.spec["cond"] and conditioning is not None) else None
         if self.spec["cond"] and ce is not None and ce.shape[0] == 1 and diffused.shape[0] > 1:
             ce = ce.expand(diffused.shape[0], -1)

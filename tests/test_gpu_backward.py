@@ -1,0 +1,162 @@
+"""GPU: the UNet input-gradient path: what autograd computes through the reference's YFCC2Model when
+losses/velocity_diffusion.py:33-61 (guided_resample_) backpropagates a loss on the denoised image to the noise.
+
+  * adjoint kernels against torch autograd of the forward op (avg-pool, bilinear x2, GroupNorm(1, C)), and <A x, y> = <x, A^T y>;
+  * engine backward on a tiny net of the family vs autograd through the fp32 oracle;
+  * the full 968 M-parameter yfcc_2 at 128x128 vs the gradient the REFERENCE's autograd produced (tests/golden/vdiff_yfcc_2_128_grad.npz);
+  * losses.VelocityDiffusion.guided_resample_ vs the same chain written with autograd over the oracle.
+Tolerance: the gradient passes through the same 16-bit layers as the forward and back again, and every ReLU mask is taken from a
+16-bit-rounded activation: a forward error of relative size e flips about a fraction e of the masks, a discrete error of relative size
+~sqrt(e) in the gradient -- bf16 relative L2 <= 1e-1 (measured 6.1e-2 tiny, 6.7e-2 full yfcc_2), cosine >= 0.995 (0.998); f16 <= 4e-2
+(2.1e-2) / 0.9995 (0.9998).  The consumer, Predictions.guided, clamps the gradient to +-clamp_value, i.e. uses its sign.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm())
+
+
+def _cos(a, b):
+    return float(F.cosine_similarity(a.double().flatten(), b.double().flatten(), dim=0))
+
+
+def _nhwc16(x, dtype):
+    return x.permute(0, 2, 3, 1).contiguous().to(dtype).to(DEV)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_adjoint_kernels_vs_autograd(dtype):
+    from perceptor_amd._hip import call, dtype_code, ptr
+    dt = dtype_code("bf16" if dtype == torch.bfloat16 else "f16")
+    g = torch.Generator().manual_seed(3)
+    n, c, h, w = 2, 16, 6, 10
+    x = torch.randn(n, c, h, w, generator=g).to(dtype).float().requires_grad_()
+    for name, fwd, oshape in (("pmi_avgpool2_bwd", lambda t: F.avg_pool2d(t, 2), (n, c, h // 2, w // 2)),
+                              ("pmi_upsample_bilinear2_bwd", lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False),
+                               (n, c, 2 * h, 2 * w))):
+        dy = torch.randn(*oshape, generator=g).to(dtype).float()
+        (ref,) = torch.autograd.grad((fwd(x) * dy).sum(), x)
+        out = torch.empty((n, h, w, c), dtype=dtype, device=DEV)
+        dyd = _nhwc16(dy, dtype)
+        call(name, ptr(dyd), ptr(out), n, h, w, c, dt)
+        got = out.float().cpu().permute(0, 3, 1, 2)
+        assert float((got - ref).abs().max()) <= 2 ** (-7 if dtype == torch.bfloat16 else -10) * float(ref.abs().max()), name
+    # GroupNorm(1, C) with affine, plus the residual path of the attention block
+    gamma, beta = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    dy = torch.randn(n, c, h, w, generator=g).to(dtype).float()
+    res = torch.randn(n, c, h, w, generator=g).to(dtype).float()
+    (ref,) = torch.autograd.grad((F.group_norm(x, 1, gamma, beta, eps=1e-5) * dy).sum(), x)
+    out = torch.empty((n, h, w, c), dtype=dtype, device=DEV)
+    gam = gamma.to(DEV)
+    xd, dyd, resd = _nhwc16(x.detach(), dtype), _nhwc16(dy, dtype), _nhwc16(res, dtype)     # named: a temporary's block is recycled by the next one
+    call("pmi_gn1_bwd", ptr(xd), ptr(dyd), ptr(gam), ptr(resd), ptr(out), n, h * w, c, 1e-5, dt)
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    assert float((got - (ref + res)).abs().max()) <= 2 ** (-6 if dtype == torch.bfloat16 else -9) * float((ref + res).abs().max())
+    a, b = torch.randn(4, 8, 8, 16, generator=g).to(dtype).to(DEV), torch.randn(4, 8, 8, 16, generator=g).to(dtype).to(DEV)
+    s = torch.empty_like(a)
+    call("pmi_add16", ptr(a), ptr(b), ptr(s), a.numel(), dt)
+    assert torch.equal(s, (a.float() + b.float()).to(dtype))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_tiny_net_input_gradient_vs_oracle_autograd(dtype):
+    from oracle import vdiff as ov
+    from perceptor_amd.engine import vdiff
+    from perceptor_amd.utils.synth import seeded_noise, synth_state_dict
+    spec = vdiff.make_spec("tiny", (3, 32, 32), [64, 128, 128], 2, 2, 4, 1, False)
+    sd = synth_state_dict(vdiff.state_dict_shapes(spec), 0)
+    eng = vdiff.VDiffEngine(spec, sd, DEV, dtype)
+    x = seeded_noise((2, 3, 32, 48), 5)
+    t = torch.tensor([0.9, 0.3])
+    probe = seeded_noise((2, 3, 32, 48), 8)
+    xr = x.clone().requires_grad_()
+    with torch.enable_grad():
+        v_ref = ov.vdiff_forward.__wrapped__(sd, ov.tiny_spec(False), xr, t)          # the oracle without its no_grad wrapper
+        (g_ref,) = torch.autograd.grad((v_ref * probe).sum(), xr)
+    img = ((x + 1) / 2).to(DEV)
+    v, tape = eng.forward_train(img, t.to(DEV))
+    assert _rel(v.cpu(), v_ref.detach()) <= 2e-2
+    # training-mode forward keeps relu(conv2) as its own 16-bit tensor before the skip add (one more rounding than the fused inference epilogue)
+    assert _rel(v.cpu(), eng.forward(img, t.to(DEV)).cpu()) <= (1e-2 if dtype == "bf16" else 2e-3)
+    g_img = eng.backward(tape, probe.to(DEV), sd)
+    g_x = g_img.cpu() / 2                                                              # images = (x + 1) / 2
+    rel, cos = _rel(g_x, g_ref), _cos(g_x, g_ref)
+    print(f"[parity] tiny v-net input gradient {dtype}: rel-L2={rel:.3e}, cos={cos:.5f}")
+    assert rel <= (1e-1 if dtype == "bf16" else 4e-2) and cos >= (0.995 if dtype == "bf16" else 0.9995)
+
+
+@pytest.mark.parametrize("dtype", ["bf16"])
+def test_yfcc2_full_input_gradient_vs_reference_autograd(dtype):
+    from perceptor_amd import models
+    from perceptor_amd.utils.synth import seeded_noise
+    g0, g = golden("vdiff_yfcc_2_128"), golden("vdiff_yfcc_2_128_grad")
+    m = models.VelocityDiffusion("yfcc_2", dtype=dtype).to(DEV)
+    img = ((g0["x"] + 1) / 2).to(DEV).requires_grad_()
+    probe = seeded_noise((1, 3, 128, 128), 46).to(DEV)
+    with torch.enable_grad():                                                          # through the public surface: autograd.Function on velocities()
+        v = m.velocities(img, g["t"].to(DEV))
+        (v * probe).sum().backward()
+    g_x = img.grad.cpu() / 2
+    rel, cos = _rel(g_x[:, :, ::2, ::2], g["g_sub"]), _cos(g_x[:, :, ::2, ::2], g["g_sub"])
+    print(f"[parity] yfcc_2@128 input gradient {dtype} vs reference autograd: rel-L2={rel:.3e}, cos={cos:.5f}")
+    assert rel <= 1e-1 and cos >= 0.995
+    f = g_x.flatten(1).double()
+    assert torch.allclose(f.norm(dim=1).float(), g["g_mom"][:, 2], rtol=5e-2)
+
+
+def test_guided_resample_matches_autograd_chain_over_the_oracle():
+    """losses.VelocityDiffusion.guided_resample_ (reference losses/velocity_diffusion.py:33-61) on a tiny net: the noise gradient
+    against autograd over diffuse -> oracle UNet -> denoised_images, then the update rule with the device noise injected."""
+    import math
+    from oracle import sampling
+    from oracle import vdiff as ov
+    from perceptor_amd import losses, models
+    from perceptor_amd.engine import sampler, vdiff
+    from perceptor_amd.utils.synth import seeded_noise
+    spec = vdiff.make_spec("tiny", (3, 32, 32), [64, 128, 128], 2, 2, 4, 1, False)
+    m = models.VelocityDiffusion("yfcc_2", spec=spec, dtype="bf16").to(DEV)
+    sd = {k: v.detach().cpu() for k, v in m.model.state_dict().items()}
+    den0 = seeded_noise((2, 3, 32, 32), 12) * 0.2 + 0.5
+    noise0 = seeded_noise((2, 3, 32, 32), 13)
+    target = seeded_noise((2, 3, 32, 32), 14) * 0.2 + 0.5
+    loss = losses.VelocityDiffusion(m, noise0.clone().to(DEV), from_ts=0.5, resample_ts=0.3)
+    torch.manual_seed(77)
+    key = sampler.rng.next_key()                                                        # the key the resample draw will take
+    torch.manual_seed(77)
+    captured = {}
+    with loss.guided_resample_(den0.to(DEV), guidance_scale=0.5, clamp_value=1e-6) as dd:
+        l = (dd - target.to(DEV)).square().mean()
+        l.backward()
+        captured["g"] = dd.grad.clone()
+    # ---- the same chain with autograd over the oracle
+    a, s = math.cos(0.5 * math.pi / 2), math.sin(0.5 * math.pi / 2)
+    nz = noise0.clone().requires_grad_()
+    with torch.enable_grad():
+        x_d = (den0 * 2 - 1) * a + nz * s
+        v = ov.vdiff_forward.__wrapped__(sd, ov.tiny_spec(False), x_d, torch.full((2,), 0.5))
+        dd_ref = ((x_d * a - v * s) + 1) / 2
+        (dd_ref - target).square().mean().backward()
+    # reproduce the update: guided(-grad) then resample_noise(0.3) with the generator's noise
+    u64 = lambda k: k & ((1 << 64) - 1)
+    rn = sampling.device_randn((2, 3, 32, 32), u64(key[0]), u64(key[1]))
+    eps_ref = (x_d * s + v * a).detach()
+    v_g = sampling.guided(v.detach(), -nz.grad, torch.full((2,), s))
+    eps_g = x_d.detach() * s + v_g * a
+    sr = math.sin(0.3 * math.pi / 2)
+    want = sampling.resample_noise(eps_g, torch.full((2,), s), torch.full((2,), sr), rn)
+    got = loss.noise.data.cpu()
+    # the guidance term is sign-like (clamp at 1e-6): compare where the reference gradient is clearly away from zero
+    sure = nz.grad.abs() > 0.25 * nz.grad.abs().mean()
+    frac = float(((got - want).abs() < 5e-2)[sure].float().mean())
+    print(f"[parity] guided_resample_: noise update agrees on {frac:.4f} of the {int(sure.sum())} elements with |grad| > mean/4; "
+          f"guidance step {float((eps_ref - eps_g).abs().max()):.3f}")
+    assert frac >= 0.98
+    assert float(loss.noise.grad.abs().max()) == 0.0                                   # zeroed at the end, as upstream
