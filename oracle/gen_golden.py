@@ -220,6 +220,22 @@ def gen_vdiff_grad():
     save("vdiff_yfcc_2_128_grad", t=t, g_sub=g[:, :, ::2, ::2].contiguous(), g_mom=moments(g), v_mom=moments(v.detach()))
 
 
+def gen_vdiff_grad_cc12m():
+    """As gen_vdiff_grad for the CLIP-conditioned CC12M1Model (GroupNorm(1, C) + Modulation2d blocks) at 64x64."""
+    cc = R.ref("models.velocity_diffusion.cc12m_1")
+    m = cc.CC12M1Model().eval()
+    m.load_state_dict(synth_like(m.state_dict(), 0))
+    for p_ in m.parameters():
+        p_.requires_grad_(False)
+    x = seeded_noise((1, 3, 64, 64), 42).requires_grad_(True)
+    t = torch.tensor([0.7])
+    ce = seeded_noise((1, 512), 43)
+    probe = seeded_noise((1, 3, 64, 64), 47)
+    v = m(x, t, ce)
+    (g,) = torch.autograd.grad((v * probe).sum(), x)
+    save("vdiff_cc12m_1_64_grad", t=t, g=g, v_mom=moments(v.detach()))
+
+
 def gen_vdiff2():
     y1 = R.ref("models.velocity_diffusion.yfcc_1")
     wa = R.ref("models.velocity_diffusion.wikiart_256")

@@ -5,7 +5,8 @@
 //   pmi_add16                   out = a + b                       (ResConvBlock's main + skip when both must be kept: yfcc_2.py:17-28)
 //   pmi_avgpool2_bwd            adjoint of nn.AvgPool2d(2)         (yfcc_2.py:101 ff.)
 //   pmi_upsample_bilinear2_bwd  adjoint of F.interpolate(x2, bilinear, align_corners=False)   (yfcc_2.py:113 ff.)
-//   pmi_gn1_bwd                 backward of GroupNorm(1, C) with affine, plus the block's residual path   (yfcc_2.py:41-52)
+//   pmi_gn1_bwd                 backward of GroupNorm(1, C) with a shared affine weight (SelfAttention2d.norm, yfcc_2.py:41-52) or a per-sample
+//                               FiLM scale (Modulation2d after GroupNorm(1, C, affine=False), cc12m_1.py:33-61), plus an optional residual path
 #include "../../include/perceptor_hip.h"
 #include "common.h"
 
@@ -92,8 +93,10 @@ __global__ __launch_bounds__(256) void upsample_bilinear2_bwd_kernel(const u16* 
 constexpr int GT = 1024;
 
 template <typename T>
-__global__ __launch_bounds__(GT) void gn1_bwd_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, const float* __restrict__ gamma,
-                                                     const u16* __restrict__ res, u16* __restrict__ dx, int64_t hw, int C, float eps) {
+__global__ __launch_bounds__(GT) void gn1_bwd_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, const float* __restrict__ gamma_,
+                                                     int gamma_ld, float gamma_add, const u16* __restrict__ res, u16* __restrict__ dx, int64_t hw,
+                                                     int C, float eps) {
+  const float* const gamma = gamma_ + (int64_t)blockIdx.x * gamma_ld;        // gamma_ld = 0: shared affine weight; > 0: per-sample (FiLM scale)
   __shared__ double red[GT / 64][4];
   __shared__ float coef[4];
   const int C8 = C >> 3;
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(GT) void gn1_bwd_kernel(const u16* __restrict__ x, 
     float p[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float g = gamma[c0 + e] * dv[e];
+      const float g = (gamma[c0 + e] + gamma_add) * dv[e];
       p[0] += xv[e]; p[1] += xv[e] * xv[e]; p[2] += g; p[3] += g * xv[e];
     }
 #pragma unroll
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(GT) void gn1_bwd_kernel(const u16* __restrict__ x, 
     unpack8<T>(*(const uint4*)(x + base + i * 8), xv);
     unpack8<T>(*(const uint4*)(dy + base + i * 8), dv);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = r * (gamma[c0 + e] * dv[e] - m1 - (xv[e] - mu) * r * m2);
+    for (int e = 0; e < 8; ++e) o[e] = r * ((gamma[c0 + e] + gamma_add) * dv[e] - m1 - (xv[e] - mu) * r * m2);
     if (res) {
       float rv[8];
       unpack8<T>(*(const uint4*)(res + base + i * 8), rv);
@@ -190,11 +193,11 @@ extern "C" int pmi_upsample_bilinear2_bwd(const void* dy, void* dx, int N, int H
   return PMI_OK;
 }
 
-/* x, dy, res (optional), dx: [N][hw][C] 16-bit; gamma [C] fp32 */
-extern "C" int pmi_gn1_bwd(const void* x, const void* dy, const float* gamma, const void* res, void* dx, int N, int64_t hw, int C, float eps,
-                           int dtype, pmi_stream_t s) {
-  if (!x || !dy || !gamma || !dx || N <= 0 || hw <= 0 || C <= 0 || (C & 7)) return PMI_ERR_ARG;
-  BY16(gn1_bwd_kernel, dim3(N), dim3(GT), (const u16*)x, (const u16*)dy, gamma, (const u16*)res, (u16*)dx, hw, C, eps);
+/* x, dy, res (optional), dx: [N][hw][C] 16-bit; the scale of channel c of sample n is gamma[n * gamma_ld + c] + gamma_add */
+extern "C" int pmi_gn1_bwd(const void* x, const void* dy, const float* gamma, int gamma_ld, float gamma_add, const void* res, void* dx, int N,
+                           int64_t hw, int C, float eps, int dtype, pmi_stream_t s) {
+  if (!x || !dy || !gamma || !dx || N <= 0 || hw <= 0 || C <= 0 || (C & 7) || gamma_ld < 0) return PMI_ERR_ARG;
+  BY16(gn1_bwd_kernel, dim3(N), dim3(GT), (const u16*)x, (const u16*)dy, gamma, gamma_ld, gamma_add, (const u16*)res, (u16*)dx, hw, C, eps);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }

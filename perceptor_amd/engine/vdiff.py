@@ -314,13 +314,11 @@ class VDiffEngine:
     # tape in reverse.  dX of a convolution is the forward convolution on transposed + flipped weights (packed lazily, once), so the
     # MFMA kernels, their fused residual add and the fragment-ordered weight paths are reused unchanged.
     def _check_backward_support(self):
-        if self.cond:
-            raise NotImplementedError("input gradient: the CLIP-conditioned nets (Modulation2d blocks, cc12m_1) are not built yet")
         if self.precise:
             raise NotImplementedError("input gradient runs in the 16-bit modes (bf16 / f16)")
         if self.spec.get("head_dim", 64) != 64 or not self.spec.get("attn_norm", True) or self.spec.get("up_mode", "bilinear") != "bilinear":
             raise NotImplementedError("input gradient: only the yfcc_2 / yfcc_1 layer set (64-channel heads, GroupNorm(1) attention, "
-                                      "bilinear upsampling) is built")
+                                      "bilinear upsampling) and cc12m_1 are built")
 
     def _wt(self, key, weight, cin_pad=None):
         """Packed weights of the input-gradient convolution of `weight` [Cout, Cin, k, k]: [Cin, Cout, k, k] with both taps flipped."""
@@ -331,7 +329,31 @@ class VDiffEngine:
             self.w[key] = PackedLinear(w.contiguous(), None, self.dt, self.device, cin_pad=cin_pad)
         return self.w[key]
 
-    def _res_train(self, l: Res, p, x, x1, tape):
+    def _res_train_cond(self, l: Res, p, x, x1, mod, tape):
+        """cc12m_1.py:46-61: conv -> GroupNorm(1, C, affine=False) -> Modulation2d -> ReLU -> conv [-> the same again] + skip, with the
+        pre-norm tensors and the post-ReLU tensors kept (norm inputs and ReLU masks of the backward)."""
+        dt, w = self.dt, self.w
+        ld = mod.stride(0)
+        h = ops.igemm(x, w[p + ".c1"], a1=x1)
+        hn = ops.group_norm(h, None, None, 1, dt, film=mod[:, l.mod1:], film_ld=ld, act=ACT_RELU)
+        if l.last:
+            skip = ops.igemm(x, w[p + ".skip"], a1=x1)
+            y = ops.igemm(hn, w[p + ".c2"], residual=skip, out_f32=True)
+            h2 = r2 = None
+        else:
+            h2 = ops.igemm(hn, w[p + ".c2"])
+            r2 = ops.group_norm(h2, None, None, 1, dt, film=mod[:, l.mod2:], film_ld=ld, act=ACT_RELU)
+            if l.cin != l.cout:
+                y = ops.igemm(x, w[p + ".skip"], a1=x1, residual=r2)
+            else:
+                y = torch.empty_like(r2)
+                call("pmi_add16", ptr(r2), ptr(x), ptr(y), r2.numel(), dt)
+        tape.append(("res", l, p, hn, r2, x1 is not None, h, h2, mod))
+        return y
+
+    def _res_train(self, l: Res, p, x, x1, tape, mod=None):
+        if self.cond:
+            return self._res_train_cond(l, p, x, x1, mod, tape)
         dt, w = self.dt, self.w
         h1 = ops.igemm(x, w[p + ".c1"], a1=x1, act=ACT_RELU)
         if l.last:
@@ -345,7 +367,7 @@ class VDiffEngine:
             else:
                 y = torch.empty_like(r2)
                 call("pmi_add16", ptr(r2), ptr(x), ptr(y), r2.numel(), dt)
-        tape.append(("res", l, p, h1, r2, x1 is not None))
+        tape.append(("res", l, p, h1, r2, x1 is not None, None, None, None))
         return y
 
     def _attn_train(self, l: Attn, p, x, tape):
@@ -364,12 +386,12 @@ class VDiffEngine:
         tape.append(("attn", l, p, x, aws, lse, a))
         return y
 
-    def _run_train(self, prog, prefix, x, tape):
+    def _run_train(self, prog, prefix, x, tape, mod=None):
         x1 = None
         for i, l in enumerate(prog):
             p = f"{prefix}.{i}"
             if isinstance(l, Res):
-                x, x1 = self._res_train(l, p, x, x1, tape), None
+                x, x1 = self._res_train(l, p, x, x1, tape, mod), None
             elif isinstance(l, Attn):
                 x = self._attn_train(l, p, x, tape)
             elif isinstance(l, Down):
@@ -380,14 +402,14 @@ class VDiffEngine:
                 tape.append(("up",))
             elif isinstance(l, Skip):
                 inner_tape = []
-                inner = self._run_train(l.main, p + ".main", x, inner_tape)
+                inner = self._run_train(l.main, p + ".main", x, inner_tape, mod)
                 tape.append(("skip", inner_tape))
                 x, x1 = inner, x                       # torch.cat([main(x), x], dim=1)   (yfcc_2.py:31-38)
         assert x1 is None
         return x
 
     @torch.no_grad()
-    def forward_train(self, images: torch.Tensor, t: torch.Tensor):
+    def forward_train(self, images: torch.Tensor, t: torch.Tensor, clip_embed: Optional[torch.Tensor] = None):
         """As forward(), keeping what backward() needs.  Returns (v NCHW fp32, tape)."""
         self._check_backward_support()
         if not images.is_cuda:
@@ -396,12 +418,17 @@ class VDiffEngine:
         images = images.float().contiguous()
         n, _, hh, ww = images.shape
         t = t.to(device=dev, dtype=torch.float32).contiguous()
+        mod = None
+        if self.cond:
+            if clip_embed is None:
+                raise ValueError("this model is CLIP-conditioned: clip_embed is required")
+            mod = self._mapping(t, clip_embed)                 # no gradient flows to the conditioning: it only scales / shifts
         planes = torch.empty((n, 16), dtype=torch.float32, device=dev)
         call("pmi_fourier_features", ptr(t), ptr(self.tw), ptr(planes), n, 8)
         x = torch.empty((n, hh, ww, 24), dtype=_hip.TORCH_DTYPE[dt], device=dev)
         call("pmi_prep_input", ptr(images), ptr(planes), 16, ptr(x), n, hh, ww, 24, dt)
         tape = []
-        y = self._run_train(self.spec["net"], "net", x, tape)
+        y = self._run_train(self.spec["net"], "net", x, tape, mod)
         out = torch.empty((n, 3, hh, ww), dtype=torch.float32, device=dev)
         call("pmi_finish_output", ptr(y), y.shape[-1], ptr(out), n, hh, ww, 3)
         return out, tape
@@ -411,9 +438,17 @@ class VDiffEngine:
         call("pmi_act_bwd", ptr(g), ptr(y), ptr(g), g.numel(), ACT_RELU, self.dt)
         return g
 
+    def _film_norm_back(self, xpre, d, mod, off):
+        """d (gradient wrt Modulation2d's output, ReLU mask already applied) -> gradient wrt the GroupNorm(1, C) input xpre."""
+        n, hh, ww, c = xpre.shape
+        out = torch.empty_like(xpre)
+        scale = mod[:, off:]                                                     # [N, >= C] view: (scale | shift) of this layer
+        call("pmi_gn1_bwd", ptr(xpre), ptr(d), scale.data_ptr(), mod.stride(0), 1.0, None, ptr(out), n, hh * ww, c, 1e-5, self.dt)
+        return out
+
     def _res_back(self, rec, g, sd, first):
-        _, l, p, h1, r2, two = rec
-        j = 2
+        _, l, p, h1, r2, two, hpre, h2pre, mod = rec
+        j = 4 if self.cond else 2
         w2 = sd[p + f".main.{j}.weight"]
         w1 = sd[p + ".main.0.weight"]
         if l.last:
@@ -421,8 +456,12 @@ class VDiffEngine:
             c2t = self._wt(p + ".c2T", w2, cin_pad=8)
         else:
             d2 = self._mask(g.clone(), r2)
+            if self.cond:
+                d2 = self._film_norm_back(h2pre, d2, mod, l.mod2)
             c2t = self._wt(p + ".c2T", w2)
         dh1 = self._mask(ops.igemm(d2, c2t), h1)
+        if self.cond:
+            dh1 = self._film_norm_back(hpre, dh1, mod, l.mod1)
         has_skip = l.cin != l.cout
         skw = sd[p + ".skip.weight"] if has_skip else None
         spad = 8 if l.last else None
@@ -451,7 +490,7 @@ class VDiffEngine:
         call("pmi_vit_attn_bwd", ptr(aws), ptr(lse), ptr(a), ptr(da), ptr(bws), ptr(delta), ptr(dqkv), n, t, heads, 64.0 ** -0.5, dt)
         dhn = ops.igemm(dqkv, self._wt(p + ".qkvT", sd[p + ".qkv_proj.weight"]))
         gx = torch.empty_like(x)
-        call("pmi_gn1_bwd", ptr(x), ptr(dhn), ptr(self.w[p + ".gn"][0]), ptr(g2), ptr(gx), n, t, c, 1e-5, dt)
+        call("pmi_gn1_bwd", ptr(x), ptr(dhn), ptr(self.w[p + ".gn"][0]), 0, 0.0, ptr(g2), ptr(gx), n, t, c, 1e-5, dt)
         return gx
 
     def _back(self, tape, g, sd, outermost=False):

@@ -51,8 +51,9 @@ class VelocityDiffusion(LossInterface):
             with diffusion.guided_resample_(images) as diffused_denoised:
                 clip(diffused_denoised).backward()
         """
+        conditioning = extra_kwargs.pop("conditioning", None)
         if extra_kwargs:
-            raise NotImplementedError("guided_resample_ with conditioning: the conditioned nets have no input-gradient pass yet")
+            raise TypeError(f"unexpected arguments {sorted(extra_kwargs)}")
         if self.noise.grad is not None:
             self.noise.grad.zero_()
         model = self.model
@@ -61,7 +62,14 @@ class VelocityDiffusion(LossInterface):
         a, s = utils.t_to_alpha_sigma(ts)
         noise = self.noise.data.to(model.device)
         from_diffused = model.diffuse(denoised, ts, noise=noise)
-        v, tape = model.engine.forward_train(from_diffused, ts)
+        ce = None
+        if model.spec["cond"]:
+            if conditioning is None:
+                raise ValueError("this model is CLIP-conditioned: pass conditioning=")
+            ce = conditioning.squeeze(dim=1).to(model.device)
+            if ce.shape[0] == 1 and n > 1:
+                ce = ce.expand(n, -1)
+        v, tape = model.engine.forward_train(from_diffused, ts, ce)
         predictions = Predictions(from_diffused_images=from_diffused, from_ts=ts, velocities=v)
         diffuse_denoise = predictions.denoised_images.detach().requires_grad_(True)
         with torch.enable_grad():

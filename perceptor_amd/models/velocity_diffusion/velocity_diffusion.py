@@ -23,15 +23,15 @@ class _Velocities(torch.autograd.Function):
     are the HIP engine's forward_train / backward (engine/vdiff.py).  Weights are frozen: no parameter gradients."""
 
     @staticmethod
-    def forward(ctx, diffused, t, model):
-        v, tape = model.engine.forward_train(diffused, t)
+    def forward(ctx, diffused, t, model, clip_embed=None):
+        v, tape = model.engine.forward_train(diffused, t, clip_embed)
         ctx.model, ctx.tape = model, tape
         return v
 
     @staticmethod
     def backward(ctx, grad_v):
         m = ctx.model
-        return m.engine.backward(ctx.tape, grad_v.contiguous(), m.model.state_dict()), None, None
+        return m.engine.backward(ctx.tape, grad_v.contiguous(), m.model.state_dict()), None, None, None
 
 
 class VelocityDiffusion(torch.nn.Module):
@@ -140,11 +140,11 @@ class VelocityDiffusion(torch.nn.Module):
             t = torch.full((diffused.shape[0],), float(t))
         elif t.ndim == 0:          # same value as the reference's float(t), without a device->host sync (HIP-graph capturable)
             t = t.reshape(1).expand(diffused.shape[0])
-        if torch.is_grad_enabled() and diffused.requires_grad:          # autograd through the UNet (guided_resample_-style scripts)
-            return _Velocities.apply(diffused, t.to(self.device), self)
         ce = conditioning.squeeze(dim=1) if (self.spec["cond"] and conditioning is not None) else None
         if self.spec["cond"] and ce is not None and ce.shape[0] == 1 and diffused.shape[0] > 1:
             ce = ce.expand(diffused.shape[0], -1)
+        if torch.is_grad_enabled() and diffused.requires_grad:          # autograd through the UNet (guided_resample_-style scripts)
+            return _Velocities.apply(diffused, t.to(self.device), self, ce.detach() if ce is not None else None)
         return eng.forward(diffused, t, ce)
 
     def forward(self, diffused_images, ts, conditioning=None) -> Predictions:

@@ -57,7 +57,7 @@ def test_adjoint_kernels_vs_autograd(dtype):
     out = torch.empty((n, h, w, c), dtype=dtype, device=DEV)
     gam = gamma.to(DEV)
     xd, dyd, resd = _nhwc16(x.detach(), dtype), _nhwc16(dy, dtype), _nhwc16(res, dtype)     # named: a temporary's block is recycled by the next one
-    call("pmi_gn1_bwd", ptr(xd), ptr(dyd), ptr(gam), ptr(resd), ptr(out), n, h * w, c, 1e-5, dt)
+    call("pmi_gn1_bwd", ptr(xd), ptr(dyd), ptr(gam), 0, 0.0, ptr(resd), ptr(out), n, h * w, c, 1e-5, dt)
     got = out.float().cpu().permute(0, 3, 1, 2)
     assert float((got - (ref + res)).abs().max()) <= 2 ** (-6 if dtype == torch.bfloat16 else -9) * float((ref + res).abs().max())
     a, b = torch.randn(4, 8, 8, 16, generator=g).to(dtype).to(DEV), torch.randn(4, 8, 8, 16, generator=g).to(dtype).to(DEV)
@@ -67,29 +67,32 @@ def test_adjoint_kernels_vs_autograd(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
-def test_tiny_net_input_gradient_vs_oracle_autograd(dtype):
+@pytest.mark.parametrize("cond", [False, True])
+def test_tiny_net_input_gradient_vs_oracle_autograd(cond, dtype):
     from oracle import vdiff as ov
     from perceptor_amd.engine import vdiff
     from perceptor_amd.utils.synth import seeded_noise, synth_state_dict
-    spec = vdiff.make_spec("tiny", (3, 32, 32), [64, 128, 128], 2, 2, 4, 1, False)
+    spec = vdiff.make_spec("tiny", (3, 32, 32), [64, 128, 128], 2, 2, 4, 1, cond)
     sd = synth_state_dict(vdiff.state_dict_shapes(spec), 0)
     eng = vdiff.VDiffEngine(spec, sd, DEV, dtype)
     x = seeded_noise((2, 3, 32, 48), 5)
     t = torch.tensor([0.9, 0.3])
+    ce = seeded_noise((2, 512), 6) if cond else None
     probe = seeded_noise((2, 3, 32, 48), 8)
     xr = x.clone().requires_grad_()
     with torch.enable_grad():
-        v_ref = ov.vdiff_forward.__wrapped__(sd, ov.tiny_spec(False), xr, t)          # the oracle without its no_grad wrapper
+        v_ref = ov.vdiff_forward.__wrapped__(sd, ov.tiny_spec(cond), xr, t, ce)        # the oracle without its no_grad wrapper
         (g_ref,) = torch.autograd.grad((v_ref * probe).sum(), xr)
     img = ((x + 1) / 2).to(DEV)
-    v, tape = eng.forward_train(img, t.to(DEV))
+    ced = ce.to(DEV) if cond else None
+    v, tape = eng.forward_train(img, t.to(DEV), ced)
     assert _rel(v.cpu(), v_ref.detach()) <= 2e-2
     # training-mode forward keeps relu(conv2) as its own 16-bit tensor before the skip add (one more rounding than the fused inference epilogue)
-    assert _rel(v.cpu(), eng.forward(img, t.to(DEV)).cpu()) <= (1e-2 if dtype == "bf16" else 2e-3)
+    assert _rel(v.cpu(), eng.forward(img, t.to(DEV), ced).cpu()) <= (1e-2 if dtype == "bf16" else 2e-3)
     g_img = eng.backward(tape, probe.to(DEV), sd)
     g_x = g_img.cpu() / 2                                                              # images = (x + 1) / 2
     rel, cos = _rel(g_x, g_ref), _cos(g_x, g_ref)
-    print(f"[parity] tiny v-net input gradient {dtype}: rel-L2={rel:.3e}, cos={cos:.5f}")
+    print(f"[parity] tiny v-net (cond={cond}) input gradient {dtype}: rel-L2={rel:.3e}, cos={cos:.5f}")
     assert rel <= (1e-1 if dtype == "bf16" else 4e-2) and cos >= (0.995 if dtype == "bf16" else 0.9995)
 
 
@@ -110,6 +113,23 @@ def test_yfcc2_full_input_gradient_vs_reference_autograd(dtype):
     assert rel <= 1e-1 and cos >= 0.995
     f = g_x.flatten(1).double()
     assert torch.allclose(f.norm(dim=1).float(), g["g_mom"][:, 2], rtol=5e-2)
+
+
+def test_cc12m1_full_input_gradient_vs_reference_autograd():
+    """The CLIP-conditioned 603 M-parameter cc12m_1 (GroupNorm(1) + Modulation2d blocks) at 64x64 vs the reference's autograd."""
+    from perceptor_amd import models
+    from perceptor_amd.utils.synth import seeded_noise
+    g0, g = golden("vdiff_cc12m_1_64"), golden("vdiff_cc12m_1_64_grad")
+    m = models.VelocityDiffusion("cc12m_1_cfg", dtype="bf16").to(DEV)
+    img = ((g0["x"] + 1) / 2).to(DEV).requires_grad_()
+    probe = seeded_noise((1, 3, 64, 64), 47).to(DEV)
+    with torch.enable_grad():
+        v = m.velocities(img, g["t"].to(DEV), g0["clip_embed"][:, None, :].to(DEV))
+        (v * probe).sum().backward()
+    g_x = img.grad.cpu() / 2
+    rel, cos = _rel(g_x, g["g"]), _cos(g_x, g["g"])
+    print(f"[parity] cc12m_1@64 input gradient bf16 vs reference autograd: rel-L2={rel:.3e}, cos={cos:.5f}")
+    assert rel <= 1.5e-1 and cos >= 0.99
 
 
 def test_guided_resample_matches_autograd_chain_over_the_oracle():
