@@ -212,13 +212,14 @@ int pmi_clamp_grad(const float* x, const float* grad, const float* lo, const flo
  * pmi_avgpool2_bwd: dy [N][H/2][W/2][C] -> dx [N][H][W][C] (nn.AvgPool2d(2)); pmi_upsample_bilinear2_bwd: dy [N][2H][2W][C] -> dx
  * [N][H][W][C] (exact adjoint of pmi_upsample_bilinear2); pmi_gn1_bwd: GroupNorm(1, C) with affine, dx = r (g - mean g - xhat mean(g xhat))
  * (+ res), g = (gamma[n * gamma_ld + c] + gamma_add) dy: gamma_ld = 0 for a shared affine weight (SelfAttention2d.norm, yfcc_2.py:41-52),
- * > 0 with gamma_add = 1 for Modulation2d's per-sample scale after GroupNorm(1, C, affine=False) (cc12m_1.py:33-61); one workgroup per
- * sample, fixed-order reduction.                       */
+ * > 0 with gamma_add = 1 for Modulation2d's per-sample scale after GroupNorm(1, C, affine=False) (cc12m_1.py:33-61); two launches
+ * (slice sums into `partial`, then every workgroup adds the slices in index order and streams its part): deterministic.                       */
 int pmi_add16(const void* a, const void* b, void* out, int64_t n, int dtype, pmi_stream_t s);
 int pmi_avgpool2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, pmi_stream_t s);
 int pmi_upsample_bilinear2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, pmi_stream_t s);
-int pmi_gn1_bwd(const void* x, const void* dy, const float* gamma, int gamma_ld, float gamma_add, const void* res, void* dx, int N,
-                int64_t hw, int C, float eps, int dtype, pmi_stream_t s);
+int pmi_gn1_bwd_partials(int64_t hw, int C);   /* slices per sample: the caller passes partial = N * this * 4 doubles of workspace */
+int pmi_gn1_bwd(const void* x, const void* dy, const float* gamma, int gamma_ld, float gamma_add, const void* res, void* dx,
+                double* partial, int N, int64_t hw, int C, float eps, int dtype, pmi_stream_t s);
 
 /* ---- CLIP guidance path (forward + input-gradient) ---------------------------------------
  * ViT arithmetic: open-clip-torch 2.0.2 visual tower == OpenAI-CLIP VisionTransformer, in-tree copy

@@ -86,35 +86,36 @@ __global__ __launch_bounds__(256) void upsample_bilinear2_bwd_kernel(const u16* 
   }
 }
 
-// GroupNorm(1, C) backward for one sample per workgroup:  y = (x - mu) * r * gamma[c] + beta[c]
+// GroupNorm(1, C) backward:  y = (x - mu) * r * gamma[c] + beta[c]
 //   g = gamma * dy;  dx = r * (g - mean(g) - xhat * mean(g * xhat)) (+ res), means over all C*HW elements of the sample.
-// Pass 1 reduces (sum x, sum x^2, sum g, sum g x) in a fixed order (per-thread serial, wave butterfly, per-wave LDS slots added in order);
-// pass 2 re-reads x and dy (L2-resident for the attention maps this runs on: <= 32x32 x 1024 channels).
-constexpr int GT = 1024;
+// Two launches: (1) P workgroups per sample reduce (sum x, sum x^2, sum g, sum g x) over their slice in a fixed order (per-thread
+// serial, wave butterfly, per-wave LDS slots added in order) into partial[n][p][4] doubles; (2) every workgroup of the apply pass adds
+// the P partials of its sample in index order (same result in every workgroup: deterministic) and streams its slice.
+constexpr int GT = 256;
 
 template <typename T>
-__global__ __launch_bounds__(GT) void gn1_bwd_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, const float* __restrict__ gamma_,
-                                                     int gamma_ld, float gamma_add, const u16* __restrict__ res, u16* __restrict__ dx, int64_t hw,
-                                                     int C, float eps) {
-  const float* const gamma = gamma_ + (int64_t)blockIdx.x * gamma_ld;        // gamma_ld = 0: shared affine weight; > 0: per-sample (FiLM scale)
+__global__ __launch_bounds__(GT) void gn1_bwd_reduce_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, const float* __restrict__ gamma_,
+                                                            int gamma_ld, float gamma_add, double* __restrict__ partial, int64_t hw, int C, int P) {
   __shared__ double red[GT / 64][4];
-  __shared__ float coef[4];
+  const int n = blockIdx.y, p = blockIdx.x;
+  const float* const gamma = gamma_ + (int64_t)n * gamma_ld;     // gamma_ld = 0: shared affine weight; > 0: per-sample (FiLM scale)
   const int C8 = C >> 3;
-  const int64_t n8 = hw * C8, base = (int64_t)blockIdx.x * hw * C;
+  const int64_t n8 = hw * C8, base = (int64_t)n * hw * C;
+  const int64_t per = (n8 + P - 1) / P, i0 = p * per, i1 = i0 + per < n8 ? i0 + per : n8;
   double s[4] = {0, 0, 0, 0};
-  for (int64_t i = threadIdx.x; i < n8; i += GT) {
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += GT) {
     const int c0 = (int)(i % C8) * 8;
     float xv[8], dv[8];
     unpack8<T>(*(const uint4*)(x + base + i * 8), xv);
     unpack8<T>(*(const uint4*)(dy + base + i * 8), dv);
-    float p[4] = {0.f, 0.f, 0.f, 0.f};
+    float q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float g = (gamma[c0 + e] + gamma_add) * dv[e];
-      p[0] += xv[e]; p[1] += xv[e] * xv[e]; p[2] += g; p[3] += g * xv[e];
+      q[0] += xv[e]; q[1] += xv[e] * xv[e]; q[2] += g; q[3] += g * xv[e];
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s[k] += (double)p[k];
+    for (int k = 0; k < 4; ++k) s[k] += (double)q[k];
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -125,20 +126,37 @@ __global__ __launch_bounds__(GT) void gn1_bwd_kernel(const u16* __restrict__ x, 
     for (int k = 0; k < 4; ++k) red[threadIdx.x >> 6][k] = s[k];
   }
   __syncthreads();
+  if (threadIdx.x < 4) {
+    double t = 0;
+    for (int w = 0; w < GT / 64; ++w) t += red[w][threadIdx.x];
+    partial[((int64_t)n * P + p) * 4 + threadIdx.x] = t;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(GT) void gn1_bwd_apply_kernel(const u16* __restrict__ x, const u16* __restrict__ dy, const float* __restrict__ gamma_,
+                                                           int gamma_ld, float gamma_add, const u16* __restrict__ res, u16* __restrict__ dx,
+                                                           const double* __restrict__ partial, int64_t hw, int C, int P, float eps) {
+  __shared__ float coef[4];
+  const int n = blockIdx.y, p = blockIdx.x;
+  const float* const gamma = gamma_ + (int64_t)n * gamma_ld;
   if (threadIdx.x == 0) {
     double t[4] = {0, 0, 0, 0};
-    for (int w = 0; w < GT / 64; ++w)
-      for (int k = 0; k < 4; ++k) t[k] += red[w][k];
+    for (int q = 0; q < P; ++q)
+      for (int k = 0; k < 4; ++k) t[k] += partial[((int64_t)n * P + q) * 4 + k];
     const double cnt = (double)hw * C;
     const double mu = t[0] / cnt, var = t[1] / cnt - mu * mu;
     const double r = 1.0 / sqrt((var > 0 ? var : 0) + (double)eps);
-    const double m1 = t[2] / cnt;                              // mean(g)
-    const double m2 = r * (t[3] - mu * t[2]) / cnt;            // mean(g * xhat)
-    coef[0] = (float)mu; coef[1] = (float)r; coef[2] = (float)m1; coef[3] = (float)m2;
+    coef[0] = (float)mu; coef[1] = (float)r;
+    coef[2] = (float)(t[2] / cnt);                             // mean(g)
+    coef[3] = (float)(r * (t[3] - mu * t[2]) / cnt);           // mean(g * xhat)
   }
   __syncthreads();
   const float mu = coef[0], r = coef[1], m1 = coef[2], m2 = coef[3];
-  for (int64_t i = threadIdx.x; i < n8; i += GT) {
+  const int C8 = C >> 3;
+  const int64_t n8 = hw * C8, base = (int64_t)n * hw * C;
+  const int64_t per = (n8 + P - 1) / P, i0 = p * per, i1 = i0 + per < n8 ? i0 + per : n8;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += GT) {
     const int c0 = (int)(i % C8) * 8;
     float xv[8], dv[8], o[8];
     unpack8<T>(*(const uint4*)(x + base + i * 8), xv);
@@ -193,11 +211,22 @@ extern "C" int pmi_upsample_bilinear2_bwd(const void* dy, void* dx, int N, int H
   return PMI_OK;
 }
 
-/* x, dy, res (optional), dx: [N][hw][C] 16-bit; the scale of channel c of sample n is gamma[n * gamma_ld + c] + gamma_add */
-extern "C" int pmi_gn1_bwd(const void* x, const void* dy, const float* gamma, int gamma_ld, float gamma_add, const void* res, void* dx, int N,
-                           int64_t hw, int C, float eps, int dtype, pmi_stream_t s) {
-  if (!x || !dy || !gamma || !dx || N <= 0 || hw <= 0 || C <= 0 || (C & 7) || gamma_ld < 0) return PMI_ERR_ARG;
-  BY16(gn1_bwd_kernel, dim3(N), dim3(GT), (const u16*)x, (const u16*)dy, gamma, gamma_ld, gamma_add, (const u16*)res, (u16*)dx, hw, C, eps);
+/* x, dy, res (optional), dx: [N][hw][C] 16-bit; the scale of channel c of sample n is gamma[n * gamma_ld + c] + gamma_add;
+ * partial: workspace of N * pmi_gn1_bwd_partials(hw, C) * 4 doubles */
+extern "C" int pmi_gn1_bwd_partials(int64_t hw, int C) {
+  const int64_t n8 = hw * (C / 8);
+  int64_t p = n8 / 4096;                                       // >= 16 pieces of 16 bytes per thread and slice
+  return (int)(p < 1 ? 1 : (p > 256 ? 256 : p));
+}
+
+extern "C" int pmi_gn1_bwd(const void* x, const void* dy, const float* gamma, int gamma_ld, float gamma_add, const void* res, void* dx,
+                           double* partial, int N, int64_t hw, int C, float eps, int dtype, pmi_stream_t s) {
+  if (!x || !dy || !gamma || !dx || !partial || N <= 0 || hw <= 0 || C <= 0 || (C & 7) || gamma_ld < 0) return PMI_ERR_ARG;
+  const int P = pmi_gn1_bwd_partials(hw, C);
+  BY16(gn1_bwd_reduce_kernel, dim3(P, N), dim3(GT), (const u16*)x, (const u16*)dy, gamma, gamma_ld, gamma_add, partial, hw, C, P);
+  PMI_CHECK_LAUNCH();
+  BY16(gn1_bwd_apply_kernel, dim3(P, N), dim3(GT), (const u16*)x, (const u16*)dy, gamma, gamma_ld, gamma_add, (const u16*)res, (u16*)dx,
+       partial, hw, C, P, eps);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }

@@ -443,7 +443,8 @@ class VDiffEngine:
         n, hh, ww, c = xpre.shape
         out = torch.empty_like(xpre)
         scale = mod[:, off:]                                                     # [N, >= C] view: (scale | shift) of this layer
-        call("pmi_gn1_bwd", ptr(xpre), ptr(d), scale.data_ptr(), mod.stride(0), 1.0, None, ptr(out), n, hh * ww, c, 1e-5, self.dt)
+        part = torch.empty((n, _hip.lib().pmi_gn1_bwd_partials(hh * ww, c), 4), dtype=torch.float64, device=xpre.device)
+        call("pmi_gn1_bwd", ptr(xpre), ptr(d), scale.data_ptr(), mod.stride(0), 1.0, None, ptr(out), ptr(part), n, hh * ww, c, 1e-5, self.dt)
         return out
 
     def _res_back(self, rec, g, sd, first):
@@ -490,7 +491,8 @@ class VDiffEngine:
         call("pmi_vit_attn_bwd", ptr(aws), ptr(lse), ptr(a), ptr(da), ptr(bws), ptr(delta), ptr(dqkv), n, t, heads, 64.0 ** -0.5, dt)
         dhn = ops.igemm(dqkv, self._wt(p + ".qkvT", sd[p + ".qkv_proj.weight"]))
         gx = torch.empty_like(x)
-        call("pmi_gn1_bwd", ptr(x), ptr(dhn), ptr(self.w[p + ".gn"][0]), 0, 0.0, ptr(g2), ptr(gx), n, t, c, 1e-5, dt)
+        part = torch.empty((n, _hip.lib().pmi_gn1_bwd_partials(t, c), 4), dtype=torch.float64, device=x.device)
+        call("pmi_gn1_bwd", ptr(x), ptr(dhn), ptr(self.w[p + ".gn"][0]), 0, 0.0, ptr(g2), ptr(gx), ptr(part), n, t, c, 1e-5, dt)
         return gx
 
     def _back(self, tape, g, sd, outermost=False):

@@ -57,7 +57,24 @@ def test_adjoint_kernels_vs_autograd(dtype):
     out = torch.empty((n, h, w, c), dtype=dtype, device=DEV)
     gam = gamma.to(DEV)
     xd, dyd, resd = _nhwc16(x.detach(), dtype), _nhwc16(dy, dtype), _nhwc16(res, dtype)     # named: a temporary's block is recycled by the next one
-    call("pmi_gn1_bwd", ptr(xd), ptr(dyd), ptr(gam), 0, 0.0, ptr(resd), ptr(out), n, h * w, c, 1e-5, dt)
+    from perceptor_amd import _hip
+    part = torch.empty((n, _hip.lib().pmi_gn1_bwd_partials(h * w, c), 4), dtype=torch.float64, device=DEV)
+    call("pmi_gn1_bwd", ptr(xd), ptr(dyd), ptr(gam), 0, 0.0, ptr(resd), ptr(out), ptr(part), n, h * w, c, 1e-5, dt)
+    # a map large enough for several slices per sample, per-sample (FiLM) scale: vs autograd of group_norm * (1 + scale)
+    n2, c2, h2, w2 = 2, 64, 48, 64
+    xb = torch.randn(n2, c2, h2, w2, generator=g).to(dtype).float().requires_grad_()
+    dyb = torch.randn(n2, c2, h2, w2, generator=g).to(dtype).float()
+    film = 0.2 * torch.randn(n2, 2 * c2, generator=g)
+    yb = F.group_norm(xb, 1, eps=1e-5) * (1 + film[:, :c2, None, None]) + film[:, c2:, None, None]
+    (refb,) = torch.autograd.grad((yb * dyb).sum(), xb)
+    xbd, dybd, filmd = _nhwc16(xb.detach(), dtype), _nhwc16(dyb, dtype), film.to(DEV)
+    outb = torch.empty((n2, h2, w2, c2), dtype=dtype, device=DEV)
+    P = _hip.lib().pmi_gn1_bwd_partials(h2 * w2, c2)
+    assert P > 1
+    partb = torch.empty((n2, P, 4), dtype=torch.float64, device=DEV)
+    call("pmi_gn1_bwd", ptr(xbd), ptr(dybd), ptr(filmd), 2 * c2, 1.0, None, ptr(outb), ptr(partb), n2, h2 * w2, c2, 1e-5, dt)
+    gotb = outb.float().cpu().permute(0, 3, 1, 2)
+    assert float((gotb - refb).abs().max()) <= 2 ** (-6 if dtype == torch.bfloat16 else -9) * float(refb.abs().max())
     got = out.float().cpu().permute(0, 3, 1, 2)
     assert float((got - (ref + res)).abs().max()) <= 2 ** (-6 if dtype == torch.bfloat16 else -9) * float((ref + res).abs().max())
     a, b = torch.randn(4, 8, 8, 16, generator=g).to(dtype).to(DEV), torch.randn(4, 8, 8, 16, generator=g).to(dtype).to(DEV)
