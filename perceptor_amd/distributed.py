@@ -2,8 +2,12 @@
 
 perceptor is single-device; the chains of a batch are independent (GroupNorm, attention and
 CLIP embeddings are per-sample), so rank r of R takes samples [r*N/R, (r+1)*N/R) of a batch whose initial
-noise is drawn once on the CPU from a single seed (as the reference draws it: guided_diffusion.py:104) —
-results are invariant to R.  The only collective is one all-gather of the final images (RCCL over xGMI when
+noise is drawn once on the CPU from a single seed (as the reference draws it: guided_diffusion.py:104), so the
+INPUTS of every chain are invariant to R, and a chain's bits do not depend on which rank or batch position it runs
+at (tested: batch permutation is bit-exact).  They do depend, at rounding level, on the per-rank batch SIZE (tile
+and split-K choices follow M): under weak scaling (fixed chains per GPU, what bench.py runs) the results are
+bit-identical for any R; re-sharding a fixed global batch changes them by 16-bit rounding noise, which the sign-like
+guidance clamp (predictions.py:147-154) can turn into isolated +-2e-6*scale flips.  The only collective is one all-gather of the final images (RCCL over xGMI when
 the backend is "nccl"; "gloo" in the CPU tests).  The CLIP loss is a mean over the GLOBAL batch
 (losses/clip/clip.py:99): pass n_total to losses.*.loss_and_grad so a shard reproduces its slice of the
 single-process gradient.
