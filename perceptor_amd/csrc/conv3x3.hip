@@ -416,9 +416,11 @@ int launch_t(const pmi_igemm_args& a, hipStream_t s, int cfg) {
 static int g_prefer0 = 1;      // pmi_set_option(2, v): prefer the 8-wave 256-channel config where the grid allows (A/B)
 static int g_force_cfg = -1;   // pmi_set_option(1, cfg): force a tile config where eligible (A/B benchmarking)
 static int g_wd = 1;           // pmi_set_option(6, v): allow the weights-direct kernel (conv_wd.hip) where fragment-ordered weights are given
+static int g_wd128 = 1;        // pmi_set_option(8, v): allow config 7 (128-channel weights-direct tiles)
 static int g_wd_mf16 = 1;      // pmi_set_option(7, v): its v_mfma_f32_16x16x32 form (config 6) rather than 32x32x16 (config 4)
 void pmi_conv3x3_allow_wd(int v) { g_wd = v; }
 void pmi_conv3x3_wd_mf16(int v) { g_wd_mf16 = v; }
+void pmi_conv3x3_wd128(int v) { g_wd128 = v; }
 void pmi_conv3x3_force_config(int cfg) { g_force_cfg = cfg; }
 void pmi_conv3x3_prefer_256(int v) { g_prefer0 = v; }
 
@@ -431,12 +433,16 @@ extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
   // config 3: at most 32 output channels (the UNet's last conv, 128 -> 6): one MFMA block column per wave
   if (a->N <= 32 && (a->N % 4) == 0 && !a->stats && !a->res_up && a->M / (a->H * a->W) * (a->H / 8) * (a->W / 32) >= 256) return 3;
   if ((a->N % 128) || a->out_f32 || (a->R && a->res_f32)) return -1;
-  if (a->Bf && g_wd && (!a->pro_a || a->C0 + a->C1 <= 2048)) {   // weights-direct kernel (its prologue coefficient table holds 2048 channels): 4 = 256-channel tiles (64-channel chunks), 5 = 128-channel tiles (32-channel chunks)
+  if (a->Bf && g_wd && (!a->pro_a || a->C0 + a->C1 <= 2048)) {   // weights-direct kernel (its prologue coefficient table holds 2048 channels): 4 / 6 = 256-channel tiles (64-channel chunks), 7 = 128-channel tiles (32-channel chunks)
     const int t8 = a->M / (a->H * a->W) * (a->H / 8) * (a->W / 32);
     const bool ok4 = (a->N % 256) == 0;
     if (g_force_cfg == 4 && ok4) return 4;
     if (g_force_cfg == 6 && ok4) return 6;
     if (g_force_cfg < 0 && ok4 && t8 * (a->N / 256) >= 192) return g_wd_mf16 ? 6 : 4;
+    // config 7: 128-channel tiles, 4 waves, 32-channel chunks, two workgroups per CU (its coefficient table holds 1024 channels)
+    const bool ok7 = g_wd_mf16 && (!a->pro_a || a->C0 + a->C1 <= 1024);
+    if (g_force_cfg == 7 && ok7) return 7;
+    if (g_force_cfg < 0 && g_wd128 && ok7 && !ok4 && t8 * (a->N / 128) >= 256) return 7;
   }
   const bool ok0 = (a->N % 256) == 0 || a->N >= 256, ok1 = (a->H % 16) == 0;
   if (g_force_cfg == 0 && ok0) return 0;

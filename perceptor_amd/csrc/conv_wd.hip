@@ -37,29 +37,34 @@ namespace {
 constexpr int PW = 34;
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <typename T, int PRO, bool MF16>
-__global__ __launch_bounds__(512, 2) void conv3x3_wd_kernel(const pmi_igemm_args a) {
-  constexpr int NWN = 8, NW = 8, NT = 512, CK = 64;
+// NWN waves x 32 channels = the tile's output channels; CK = input channels per staged chunk.  (8, 64): one 8-wave workgroup per CU,
+// 256-channel tiles (configs 4 / 6).  (4, 32): 128-channel tiles for the 128-channel layers, 4 waves and ~75 KB of LDS, so TWO
+// workgroups share a CU and one's prologue / epilogue runs under the other's main loop (config 7; 16x16x32 MFMA only).
+template <typename T, int PRO, bool MF16, int NWN = 8, int CK = 64>
+__global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm_args a) {
+  constexpr int NW = NWN, NT = NW * 64;
+  constexpr int KS = MF16 ? CK / 32 : CK / 16;         // k-steps (one MFMA deep) per chunk
   constexpr int PP = 10 * PW;                          // patch pixels
   constexpr int CPR = CK / 8;                          // 16-byte chunks per patch pixel
-  constexpr int NG = 12;                               // groups per chunk: 3 dx x 4 steps of 16 channels, or 3 dx x 2 steps of 32 x 2 half-rows
-  constexpr int WGC = MF16 ? 6 : 12;                   // weight groups per chunk (3 dy fragments of 1 KB each, x 2 channel blocks with MF16)
+  constexpr int NG = MF16 ? 3 * KS * 2 : 3 * KS;       // groups per chunk: 3 dx x k-steps (x 2 half-rows with 16x16x32); 12 at CK = 64
+  constexpr int WGC = 3 * KS;                          // weight groups per chunk (3 dy fragments of 1 KB each, x 2 channel blocks with MF16)
   constexpr int NWF = MF16 ? 6 : 3;                    // fragments per weight group
   constexpr int GB = NWF * 1024;
   constexpr int NPI = (PP * CPR + NT - 1) / NT;        // 16-byte staging pieces per thread per chunk (6)
-  constexpr int ROW = CK * 2 + (MF16 ? 32 : 16);       // patch row pitch in bytes
+  constexpr int ROW = CK * 2 + ((MF16 && CK == 64) ? 32 : 16);   // patch row pitch in bytes: 144 / 160 / 80, conflict-free for the b128 fragment reads
   constexpr int PATCH_BYTES = (NPI * NT / CPR) * ROW;  // padded to whole staging passes: no bounds test on the LDS writes
   constexpr int BN = NWN * 32, NPX = 256;
   constexpr int SROW = BN * 2 + 16;                    // epilogue staging row: BN 16-bit channels + 16 B pad
   constexpr int EPI_BYTES = NPX * SROW + NW * BN * 8 + BN * 4;
-  constexpr int MAXCIN = 2048;                         // fused-prologue coefficient table: a[Cin], b[Cin] fp32 of this image
+  constexpr int MAXCIN = NWN == 8 ? 2048 : 1024;       // fused-prologue coefficient table: a[Cin], b[Cin] fp32 of this image
   constexpr int COEF_BYTES = PRO ? 2 * MAXCIN * 4 : 0;
   constexpr int PPIX_BYTES = NPI * NT * 4;             // source pixel of every staged piece of this thread (kept out of the registers)
   // Staging of the next patch: store slot k (k = 0..NPI-1) is group SG k; the piece it stores was loaded one slot earlier into
   // the single carried register set (piece 0 in the previous chunk's last group).  With MF16 the store slots are the half-row-0
   // groups, where only ONE weight set is live, so the prologue's temporaries fit the register file.
-  constexpr int SG = MF16 ? 2 : 1;
-  static_assert(SG * (NPI - 1) <= NG - 2, "the next patch must be complete before the barrier in the chunk's last group");
+  constexpr int SG = (MF16 && 2 * (NPI - 1) <= NG - 2) ? 2 : 1;
+  static_assert(SG * (NPI - 1) <= NG - 1, "the next patch must be complete before the barrier in the chunk's last group");
+  static_assert(2 * PATCH_BYTES + COEF_BYTES + PPIX_BYTES <= (NWN == 8 ? 160 : 80) * 1024 && EPI_BYTES <= (NWN == 8 ? 160 : 80) * 1024, "LDS budget");
   __shared__ __attribute__((aligned(16))) char smem[cmax(2 * PATCH_BYTES + COEF_BYTES + PPIX_BYTES, EPI_BYTES)];
   float* const coef = (float*)(smem + 2 * PATCH_BYTES);
   int* const ppix_s = (int*)(smem + 2 * PATCH_BYTES + COEF_BYTES);
@@ -110,13 +115,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wd_kernel(const pmi_igemm_args
     const bool inside = pp < PP && (unsigned)sy < (unsigned)a.H && (unsigned)sx < (unsigned)a.W;
     ppix_s[i * NT + tid] = inside ? (sy >> a.up) * a.Win + (sx >> a.up) : -1;
   }
-  if (PRO) {
-    for (int c = tid; c < Cin; c += NT) {
-      coef[c] = a.pro_a[(int64_t)img * Cin + c];
-      coef[MAXCIN + c] = a.pro_b[(int64_t)img * Cin + c];
-    }
-    __syncthreads();
-  }
+  // (the coefficient table is filled in the prologue below, AFTER the first patch loads are in flight: one memory latency, not two)
 
   // source of chunk `chunk`: which tensor, row pitch, channel offset (wave-uniform: C0 is a multiple of CK)
   auto load_piece = [&](int chunk, int pix, bool live) -> uint4 {        // !live: out-of-range offset, zeros, no traffic, no branch
@@ -170,9 +169,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wd_kernel(const pmi_igemm_args
   {
     uint4 p0[NPI];
     float ga[8], gb[8];
-    if (PRO) read_coef(0, ga, gb);
 #pragma unroll
-    for (int i = 0; i < NPI; ++i) p0[i] = load_piece(0, ppix_s[i * NT + tid], true);
+    for (int i = 0; i < NPI; ++i) p0[i] = load_piece(0, ppix_s[i * NT + tid], true);      // (a thread reads only its own table entries)
+    if (PRO) {
+      for (int c = tid; c < Cin; c += NT) {
+        coef[c] = a.pro_a[(int64_t)img * Cin + c];
+        coef[MAXCIN + c] = a.pro_b[(int64_t)img * Cin + c];
+      }
+      __syncthreads();
+      read_coef(0, ga, gb);
+    }
 #pragma unroll
     for (int i = 0; i < NPI; ++i) store_piece(smem, i, p0[i], ppix_s[i * NT + tid], ga, gb);
   }
@@ -184,8 +190,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wd_kernel(const pmi_igemm_args
   const int frag0 = MF16 ? (lane & 15) * ROW + (lane >> 4) * 16 : l31 * ROW + lhi * 16;
   // byte offset of group g's fragments relative to frag0: 32x32x16: (dx, 16-channel step); 16x16x32: (dx, 32-channel step, half-row)
   auto goff = [&](int g) -> int {
-    if (MF16) { const int q = g >> 1, s = g & 1; return (q / 2) * ROW + (q % 2) * 64 + s * 16 * ROW; }
-    return (g / 4) * ROW + (g % 4) * 32;
+    if (MF16) { const int q = g >> 1, s = g & 1; return (q / KS) * ROW + (q % KS) * 64 + s * 16 * ROW; }
+    return (g / KS) * ROW + (g % KS) * 32;
   };
   // Six fragment registers as a rolling window over the 10 patch rows of a group: row i's MFMAs need rows i, i+1, i+2; once they
   // have issued, row i's register is reloaded -- with row i+6 of this group (i < 4), or with row i-4 of the NEXT group (i = 4, 5, 6;
@@ -202,7 +208,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wd_kernel(const pmi_igemm_args
   int pixc = ppix_s[0 * NT + tid];
   uint4 pr = load_piece(nchunks > 1 ? 1 : 0, pixc, nchunks > 1);      // piece 0 of the second chunk's patch
   int pixn = ppix_s[1 * NT + tid];
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
+  // With an odd number of weight groups per chunk (CK = 32: 3) the two-slot weight ring changes phase from chunk to chunk; the ring slot
+  // must be a compile-time register index, so the chunk body is unrolled over both phases and the loop advances two chunks at a time
+  // (Cin is a multiple of 64: the chunk count is even).
+  constexpr int CSTEP = (MF16 && (WGC & 1)) ? 2 : 1;
+  for (int chunk0 = 0; chunk0 < nchunks; chunk0 += CSTEP) {
+#pragma unroll
+   for (int ph = 0; ph < CSTEP; ++ph) {                  // fully unrolled: PH is a constant in each copy of the body
+    const int chunk = chunk0 + ph;
+    const int PH = (ph * WGC) & 1;                       // parity of this chunk's first weight-group index
     const char* const pb = smem + (chunk & 1) * PATCH_BYTES;
     char* const pn = smem + ((chunk + 1) & 1) * PATCH_BYTES;
     const bool more = chunk + 1 < nchunks;              // past the end the staging runs on zeros into the unused buffer (no branches
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wd_kernel(const pmi_igemm_args
     const int gbase = chunk * WGC;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      if (MF16) { if ((g & 1) == 0) load_wg(((g >> 1) + 1) & 1, gbase + (g >> 1) + 1); }     // the next (dx, step) pair, one pair ahead
+      if (MF16) { if ((g & 1) == 0) load_wg(((g >> 1) + 1 + PH) & 1, gbase + (g >> 1) + 1); }     // the next (dx, step) pair, one pair ahead
       else load_wg((g + 2) % 3, gbase + g + 2);                                              // two groups ahead
       const bool store_slot = g % SG == 0 && g / SG < NPI;            // stores piece g / SG from `pr`
       const int lp = (g + 1 == NG) ? 0 : (g - (SG - 1)) / SG + 1;     // piece whose load is issued in this group (if load_slot)
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wd_kernel(const pmi_igemm_args
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
               for (int cb = 0; cb < 2; ++cb)
-                acc4[i][g & 1][cb] = T::mfma16(wq[(g >> 1) & 1][dy * 2 + cb], xf[(i + dy + 4 * g) % 6], acc4[i][g & 1][cb]);
+                acc4[i][g & 1][cb] = T::mfma16(wq[((g >> 1) + PH) & 1][dy * 2 + cb], xf[(i + dy + 4 * g) % 6], acc4[i][g & 1][cb]);
           } else {
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) acc[i] = T::mfma32(wq[g % 3][dy], xf[(i + dy + 4 * g) % 6], acc[i]);
@@ -272,6 +286,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wd_kernel(const pmi_igemm_args
       pr = prn; pixc = pixl; pixn = pixn2;
       __builtin_amdgcn_sched_barrier(0);
     }
+   }
   }
 
   CSTAMP(1);
@@ -287,13 +302,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wd_kernel(const pmi_igemm_args
     if (a.nbias) b += a.nbias[(int64_t)img * (a.ldnb ? a.ldnb : a.N) + n];
     bsm[c] = b;
   }
-  constexpr int NWI = 16;                              // store instructions per wave: 2 pixel rows (512 B each) per instruction
-  const int q = lane & 31, psub = lane >> 5;
+  constexpr int LPR = BN / 8;                          // lanes per output pixel row (16 bytes each): 32 / 16
+  constexpr int PPI = 64 / LPR;                        // pixels per store instruction: 2 / 4
+  constexpr int PXW = NPX / NW;                        // pixels written out by a wave: 32 / 64
+  constexpr int NWI = PXW / PPI;                       // store instructions per wave (16)
+  const int q = lane % LPR, psub = lane / LPR;
   const int cl0 = q * 8;
   uint4 rres[NWI];
 #pragma unroll
   for (int t = 0; t < NWI; ++t) {                      // residual loads fly while the accumulators are staged
-    const int p = wid * 32 + t * 2 + psub;
+    const int p = wid * PXW + t * PPI + psub;
     const int y = y0 + (p >> 5), x = x0 + (p & 31);
     rres[t] = make_uint4(0, 0, 0, 0);
     if (a.R) {
@@ -349,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wd_kernel(const pmi_igemm_args
   for (int e = 0; e < 16; ++e) cs[e] = 0.f;
 #pragma unroll
   for (int t = 0; t < NWI; ++t) {
-    const int p = wid * 32 + t * 2 + psub;
+    const int p = wid * PXW + t * PPI + psub;
     uint4 v = *(const uint4*)(stg + p * SROW + cl0 * 2);
     if (a.R || a.stats) {
       float f[8];
@@ -370,8 +388,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wd_kernel(const pmi_igemm_args
   STAMP(7);
   if (a.stats) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) cs[e] += __shfl_xor(cs[e], 32);
-    if (lane < 32) {
+    for (int e = 0; e < 16; ++e) {
+      cs[e] += __shfl_xor(cs[e], 32);
+      if (LPR == 16) cs[e] += __shfl_xor(cs[e], 16);
+    }
+    if (lane < LPR) {
       float* const slot = stat + (wid * BN + cl0) * 2;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { slot[2 * e] = cs[e]; slot[2 * e + 1] = cs[8 + e]; }
@@ -400,6 +421,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wd_kernel(const pmi_igemm_args
 template <typename T, int PRO>
 int launch_p(const pmi_igemm_args& a, hipStream_t s, int cfg) {
   const int nimg = a.M / (a.H * a.W);
+  if (cfg == 7) {                                      // 128-channel tiles, two 4-wave workgroups per CU
+    hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, true, 4, 32>), dim3(nimg * (a.H / 8) * (a.W / 32) * (a.N / 128)), dim3(256), 0, s, a);
+    PMI_CHECK_LAUNCH();
+    return PMI_OK;
+  }
   const int tiles = nimg * (a.H / 8) * (a.W / 32) * (a.N / 256);
   if (cfg == 6) hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, true>), dim3(tiles), dim3(512), 0, s, a);    // v_mfma_f32_16x16x32
   else hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, false>), dim3(tiles), dim3(512), 0, s, a);             // config 4: 32x32x16

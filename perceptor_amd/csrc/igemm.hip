@@ -540,6 +540,7 @@ int pmi_gemm_wd_tile_rows(const pmi_igemm_args* a, int splitk);
 int pmi_gemm_wd_launch(const pmi_igemm_args* a, void* stream);
 void pmi_conv3x3_allow_wd(int v);
 void pmi_conv3x3_wd_mf16(int v);
+void pmi_conv3x3_wd128(int v);
 void pmi_conv3x3_force_config(int cfg);
 void pmi_conv3x3_prefer_256(int v);
 static int g_allow_halo = 1;
@@ -585,6 +586,7 @@ extern "C" int pmi_set_option(int key, int value) {
   if (key == 2) { pmi_conv3x3_prefer_256(value); return 0; }
   if (key == 6) { pmi_conv3x3_allow_wd(value); return 0; }
   if (key == 7) { pmi_conv3x3_wd_mf16(value); return 0; }
+  if (key == 8) { pmi_conv3x3_wd128(value); return 0; }
   return PMI_ERR_ARG;
 }
 

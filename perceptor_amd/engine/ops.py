@@ -196,8 +196,10 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
     a.dtype = dt
     if conv and lin.taps == 9 and stride == 1 and HALO_ENABLED and WD_ENABLED and lin.n_p % 128 == 0 and lin.cin_p % 64 == 0:
         a.Bf = 1                       # ask which tile config the weights-direct kernel would run, then hand it that packing
+        a.pro_a = 1 if (prologue is not None and not lin.split) else None     # (the table size limit depends on a fused prologue)
         cfg = _hip.lib().pmi_conv3x3_halo_config(C.byref(a))
-        a.Bf = ptr(lin.frag16(64)) if cfg == 6 else ptr(lin.frag(64)) if cfg == 4 else None
+        a.pro_a = None
+        a.Bf = ptr(lin.frag16(64)) if cfg == 6 else ptr(lin.frag16(32)) if cfg == 7 else ptr(lin.frag(64)) if cfg == 4 else None
     if GEMM_WD_ENABLED and lin.taps == 1 and not lin.split and not up and stride == 1 and a1 is None and lin.n_p % 256 == 0 and lin.K % 128 == 0 \
             and nbias is None and not want_stats and prologue is None:
         a.Bf = ptr(lin.frag_gemm())            # plain GEMM: weights-direct kernel (csrc/gemm_wd.hip)
