@@ -443,6 +443,9 @@ extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
     const bool ok7 = g_wd_mf16 && (!a->pro_a || a->C0 + a->C1 <= 1024);
     if (g_force_cfg == 7 && ok7) return 7;
     if (g_force_cfg < 0 && g_wd128 && ok7 && !ok4 && t8 * (a->N / 128) >= 256) return 7;
+    // 256-multiple Cout on a map too small for the 256-channel tiles (32x32 at batch 8): the 128-channel tiles give twice the workgroups
+    // and measure 5-10 % ahead of the halo kernel's 4-wave config there
+    if (g_force_cfg < 0 && g_wd128 && ok7 && ok4 && t8 * (a->N / 128) >= 128) return 7;
   }
   const bool ok0 = (a->N % 256) == 0 || a->N >= 256, ok1 = (a->H % 16) == 0;
   if (g_force_cfg == 0 && ok0) return 0;
