@@ -218,6 +218,7 @@ int pmi_clamp_grad(const float* x, const float* grad, const float* lo, const flo
 int pmi_add16(const void* a, const void* b, void* out, int64_t n, int dtype, pmi_stream_t s);
 int pmi_avgpool2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, pmi_stream_t s);
 int pmi_upsample_bilinear2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, pmi_stream_t s);
+int pmi_upsample_nearest2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, pmi_stream_t s);   /* wikiart_256.py:117 */
 int pmi_gn1_bwd_partials(int64_t hw, int C);   /* slices per sample: the caller passes partial = N * this * 4 doubles of workspace */
 int pmi_gn1_bwd(const void* x, const void* dy, const float* gamma, int gamma_ld, float gamma_add, const void* res, void* dx,
                 double* partial, int N, int64_t hw, int C, float eps, int dtype, pmi_stream_t s);

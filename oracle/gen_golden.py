@@ -236,6 +236,21 @@ def gen_vdiff_grad_cc12m():
     save("vdiff_cc12m_1_64_grad", t=t, g=g, v_mom=moments(v.detach()))
 
 
+def gen_vdiff_grad_wikiart():
+    """As gen_vdiff_grad for WikiArt256Model (no normalisation, 128-channel heads, nearest upsampling, skip-first concat) at 64x64."""
+    wa = R.ref("models.velocity_diffusion.wikiart_256")
+    m = wa.WikiArt256Model().eval()
+    m.load_state_dict(synth_like(m.state_dict(), 0, 0.6))
+    for p_ in m.parameters():
+        p_.requires_grad_(False)
+    x = seeded_noise((1, 3, 64, 64), 45).requires_grad_(True)
+    t = torch.tensor([0.6])
+    probe = seeded_noise((1, 3, 64, 64), 48)
+    v = m(x, t)
+    (g,) = torch.autograd.grad((v * probe).sum(), x)
+    save("vdiff_wikiart_64_grad", t=t, g=g, v_mom=moments(v.detach()))
+
+
 def gen_vdiff2():
     y1 = R.ref("models.velocity_diffusion.yfcc_1")
     wa = R.ref("models.velocity_diffusion.wikiart_256")

@@ -101,6 +101,7 @@ _PROTOS = {
     "pmi_add16": ([_P, _P, _P, _L, _I, _P],),
     "pmi_avgpool2_bwd": ([_P, _P, _I, _I, _I, _I, _I, _P],),
     "pmi_upsample_bilinear2_bwd": ([_P, _P, _I, _I, _I, _I, _I, _P],),
+    "pmi_upsample_nearest2_bwd": ([_P, _P, _I, _I, _I, _I, _I, _P],),
     "pmi_gn1_bwd_partials": ([_L, _I],),
     "pmi_gn1_bwd": ([_P, _P, _P, _I, _F, _P, _P, _P, _I, _L, _I, _F, _I, _P],),
     # CLIP path (clip.hip)

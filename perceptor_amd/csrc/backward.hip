@@ -5,6 +5,7 @@
 //   pmi_add16                   out = a + b                       (ResConvBlock's main + skip when both must be kept: yfcc_2.py:17-28)
 //   pmi_avgpool2_bwd            adjoint of nn.AvgPool2d(2)         (yfcc_2.py:101 ff.)
 //   pmi_upsample_bilinear2_bwd  adjoint of F.interpolate(x2, bilinear, align_corners=False)   (yfcc_2.py:113 ff.)
+//   pmi_upsample_nearest2_bwd   adjoint of nn.Upsample(2, 'nearest')                          (wikiart_256.py:117)
 //   pmi_gn1_bwd                 backward of GroupNorm(1, C) with a shared affine weight (SelfAttention2d.norm, yfcc_2.py:41-52) or a per-sample
 //                               FiLM scale (Modulation2d after GroupNorm(1, C, affine=False), cc12m_1.py:33-61), plus an optional residual path
 #include "../../include/perceptor_hip.h"
@@ -40,6 +41,29 @@ __global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const u16* __restrict
 #pragma unroll
     for (int e = 0; e < 8; ++e) f[e] *= 0.25f;
     *(uint4*)(dx + pix * C + c8 * 8) = pack8<T>(f);
+  }
+}
+
+// Adjoint of nn.Upsample(2, 'nearest'): dx[y][x] = sum of the 2x2 block of dy
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_nearest2_bwd_kernel(const u16* __restrict__ dy, u16* __restrict__ dx, int N, int H, int W, int C) {
+  const int C8 = C >> 3, Wo = 2 * W;
+  const int64_t total = (int64_t)N * H * W * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int n = (int)(pix / ((int64_t)H * W));
+    const int rem = (int)(pix - (int64_t)n * H * W);
+    const int y = rem / W, x = rem - y * W;
+    const u16* b = dy + (((int64_t)n * 2 * H + 2 * y) * Wo + 2 * x) * C + c8 * 8;
+    float a0[8], a1[8], a2[8], a3[8];
+    unpack8<T>(*(const uint4*)b, a0);
+    unpack8<T>(*(const uint4*)(b + C), a1);
+    unpack8<T>(*(const uint4*)(b + (int64_t)Wo * C), a2);
+    unpack8<T>(*(const uint4*)(b + (int64_t)Wo * C + C), a3);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a0[e] = (a0[e] + a1[e]) + (a2[e] + a3[e]);
+    *(uint4*)(dx + pix * C + c8 * 8) = pack8<T>(a0);
   }
 }
 
@@ -207,6 +231,14 @@ extern "C" int pmi_avgpool2_bwd(const void* dy, void* dx, int N, int H, int W, i
 extern "C" int pmi_upsample_bilinear2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, pmi_stream_t s) {
   if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || (C & 7)) return PMI_ERR_ARG;
   BY16(upsample_bilinear2_bwd_kernel, dim3(grid_for((int64_t)N * H * W * (C / 8))), dim3(256), (const u16*)dy, (u16*)dx, N, H, W, C);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+
+/* dy [N][2H][2W][C] -> dx [N][H][W][C] */
+extern "C" int pmi_upsample_nearest2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, pmi_stream_t s) {
+  if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || (C & 7)) return PMI_ERR_ARG;
+  BY16(upsample_nearest2_bwd_kernel, dim3(grid_for((int64_t)N * H * W * (C / 8))), dim3(256), (const u16*)dy, (u16*)dx, N, H, W, C);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }

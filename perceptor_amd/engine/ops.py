@@ -396,6 +396,62 @@ def attention(qkv: torch.Tensor, heads: int, order: int, dt: int) -> torch.Tenso
     return out
 
 
+def _transpose16(src: torch.Tensor, off: int, rows: int, cols: int, ld: int, s_o: int, s_i: int, inner: int, batch: int) -> torch.Tensor:
+    rp = (rows + 7) // 8 * 8
+    out = _empty((batch, cols, rp), src.dtype, src.device)
+    call("pmi_transpose_16", src.data_ptr() + off * src.element_size(), ptr(out), rows, cols, ld, s_o, s_i, inner, batch)
+    return out
+
+
+def attention_train(qkv: torch.Tensor, heads: int, dt: int):
+    """Self-attention for any head dim, channels (q|k|v, head, d), keeping the softmax for attention_backward:
+    qkv [N, T, 3C] 16-bit -> (out [N, T, C], P [N*heads, T, Tp] 16-bit).  Batched MFMA GEMMs + softmax (as `attention`, order 1)."""
+    n, t, c3 = qkv.shape
+    c = c3 // 3
+    d = c // heads
+    tp = (t + 7) // 8 * 8
+    dev = qkv.device
+    sc = _empty((n * heads, t, tp), torch.float32, dev)
+    bgemm(qkv, qkv, sc, M=t, N=t, K=d, lda=c3, ldb=c3, ldd=tp, batch=n * heads, batch_inner=heads,
+          sA=(t * c3, d), sB=(t * c3, d), sD=(heads * t * tp, t * tp), dt=dt, b_off=c)
+    p = _empty((n * heads, t, tp), qkv.dtype, dev)
+    call("pmi_softmax_fwd", ptr(sc), ptr(p), n * heads * t, t, tp, tp, float(d) ** -0.5, dt)
+    vt = _transpose16(qkv, 2 * c, t, d, c3, t * c3, d, heads, n * heads)
+    out = _empty((n, t, c), qkv.dtype, dev)
+    bgemm(p, vt, out, M=t, N=d, K=tp, lda=tp, ldb=tp, ldd=c, batch=n * heads, batch_inner=heads,
+          sA=(heads * t * tp, t * tp), sB=(heads * d * tp, d * tp), sD=(t * c, d), dt=dt)
+    return out, p
+
+
+def attention_backward(qkv: torch.Tensor, p: torch.Tensor, d_out: torch.Tensor, heads: int, dt: int) -> torch.Tensor:
+    """d loss / d qkv [N, T, 3C] from d loss / d out [N, T, C] and the saved softmax P (the same five products autograd forms:
+    dP = dO V^T, dS = softmax'(P, dP), dV = P^T dO, dQ = dS K, dK = dS^T Q, scale folded into softmax_bwd)."""
+    n, t, c3 = qkv.shape
+    c = c3 // 3
+    d = c // heads
+    tp = (t + 7) // 8 * 8
+    dev = qkv.device
+    da = d_out.reshape(n * t, c)
+    dqkv = _empty((n, t, c3), qkv.dtype, dev)
+    dp = _empty((n * heads, t, tp), torch.float32, dev)
+    bgemm(da, qkv, dp, M=t, N=t, K=d, lda=c, ldb=c3, ldd=tp, batch=n * heads, batch_inner=heads,
+          sA=(t * c, d), sB=(t * c3, d), sD=(heads * t * tp, t * tp), dt=dt, b_off=2 * c)
+    ds = _empty((n * heads, t, tp), qkv.dtype, dev)
+    call("pmi_softmax_bwd", ptr(dp), ptr(p), ptr(ds), n * heads * t, t, tp, tp, float(d) ** -0.5, dt)
+    pt = _transpose16(p, 0, t, t, tp, heads * t * tp, t * tp, heads, n * heads)
+    dot = _transpose16(da, 0, t, d, c, t * c, d, heads, n * heads)
+    bgemm(pt, dot, dqkv, M=t, N=d, K=tp, lda=tp, ldb=tp, ldd=c3, batch=n * heads, batch_inner=heads,
+          sA=(heads * t * tp, t * tp), sB=(heads * d * tp, d * tp), sD=(t * c3, d), dt=dt, d_off=2 * c)        # dV
+    kt = _transpose16(qkv, c, t, d, c3, t * c3, d, heads, n * heads)
+    bgemm(ds, kt, dqkv, M=t, N=d, K=tp, lda=tp, ldb=tp, ldd=c3, batch=n * heads, batch_inner=heads,
+          sA=(heads * t * tp, t * tp), sB=(heads * d * tp, d * tp), sD=(t * c3, d), dt=dt)                     # dQ
+    dst = _transpose16(ds, 0, t, t, tp, heads * t * tp, t * tp, heads, n * heads)
+    qt = _transpose16(qkv, 0, t, d, c3, t * c3, d, heads, n * heads)
+    bgemm(dst, qt, dqkv, M=t, N=d, K=tp, lda=tp, ldb=tp, ldd=c3, batch=n * heads, batch_inner=heads,
+          sA=(heads * t * tp, t * tp), sB=(heads * d * tp, d * tp), sD=(t * c3, d), dt=dt, d_off=c)            # dK
+    return dqkv
+
+
 def gemm_f32(A: torch.Tensor, B: torch.Tensor, D: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldb: int, ldd: int, trans_b: bool = False,
              bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, alpha: float = 1.0, batch: int = 1, batch_inner: int = 1,
              sA=(0, 0), sB=(0, 0), sD=(0, 0), a_off: int = 0, b_off: int = 0, d_off: int = 0, residual: Optional[torch.Tensor] = None) -> torch.Tensor:

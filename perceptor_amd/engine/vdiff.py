@@ -316,9 +316,6 @@ class VDiffEngine:
     def _check_backward_support(self):
         if self.precise:
             raise NotImplementedError("input gradient runs in the 16-bit modes (bf16 / f16)")
-        if self.spec.get("head_dim", 64) != 64 or not self.spec.get("attn_norm", True) or self.spec.get("up_mode", "bilinear") != "bilinear":
-            raise NotImplementedError("input gradient: only the yfcc_2 / yfcc_1 layer set (64-channel heads, GroupNorm(1) attention, "
-                                      "bilinear upsampling) and cc12m_1 are built")
 
     def _wt(self, key, weight, cin_pad=None):
         """Packed weights of the input-gradient convolution of `weight` [Cout, Cin, k, k]: [Cin, Cout, k, k] with both taps flipped."""
@@ -373,17 +370,26 @@ class VDiffEngine:
     def _attn_train(self, l: Attn, p, x, tape):
         dt, w = self.dt, self.w
         n, hh, ww, c = x.shape
-        t, heads = hh * ww, c // 64
-        g, b = w[p + ".gn"]
-        hn = ops.group_norm(x, g, b, 1, dt)
+        d = self.spec.get("head_dim", 64)
+        t, heads = hh * ww, c // d
+        hn = x
+        if self.spec.get("attn_norm", True):
+            g, b = w[p + ".gn"]
+            hn = ops.group_norm(x, g, b, 1, dt)
         qkv = ops.igemm(hn.view(n * t, c), w[p + ".qkv"])
-        tp32 = (t + 31) // 32 * 32
-        aws = torch.empty((6, n * heads, tp32, 64), dtype=x.dtype, device=x.device)
-        lse = torch.empty((n * heads, tp32), dtype=torch.float32, device=x.device)
-        a = torch.empty((n * t, c), dtype=x.dtype, device=x.device)
-        call("pmi_vit_attn_fwd", ptr(qkv), ptr(aws), ptr(lse), ptr(a), n, t, heads, 64.0 ** -0.5, dt)
+        if d == 64:                                  # flash-style forward keeping the log-sum-exp (csrc/attn.hip)
+            tp32 = (t + 31) // 32 * 32
+            aws = torch.empty((6, n * heads, tp32, 64), dtype=x.dtype, device=x.device)
+            lse = torch.empty((n * heads, tp32), dtype=torch.float32, device=x.device)
+            a = torch.empty((n * t, c), dtype=x.dtype, device=x.device)
+            call("pmi_vit_attn_fwd", ptr(qkv), ptr(aws), ptr(lse), ptr(a), n, t, heads, 64.0 ** -0.5, dt)
+            saved = (aws, lse, a)
+        else:                                        # other head dims (wikiart: 128): batched GEMMs, the softmax is kept
+            a, pm = ops.attention_train(qkv.view(n, t, 3 * c), heads, dt)
+            a = a.view(n * t, c)
+            saved = (qkv, pm)
         y = ops.igemm(a, w[p + ".out"], residual=x.view(n * t, c)).view(n, hh, ww, c)
-        tape.append(("attn", l, p, x, aws, lse, a))
+        tape.append(("attn", l, p, x, saved))
         return y
 
     def _run_train(self, prog, prefix, x, tape, mod=None):
@@ -398,13 +404,14 @@ class VDiffEngine:
                 x = ops.avgpool2(x, self.dt)
                 tape.append(("down",))
             elif isinstance(l, Up):
-                x = ops.upsample_bilinear2(x, self.dt)
+                x = ops.upsample_nearest2(x) if self.spec.get("up_mode") == "nearest" else ops.upsample_bilinear2(x, self.dt)
                 tape.append(("up",))
             elif isinstance(l, Skip):
                 inner_tape = []
                 inner = self._run_train(l.main, p + ".main", x, inner_tape, mod)
                 tape.append(("skip", inner_tape))
-                x, x1 = inner, x                       # torch.cat([main(x), x], dim=1)   (yfcc_2.py:31-38)
+                # torch.cat([main(x), x], dim=1) (yfcc_2.py:31-38); wikiart concatenates the other way round (wikiart_256.py:86-87)
+                x, x1 = (x, inner) if self.spec.get("skip_first") else (inner, x)
         assert x1 is None
         return x
 
@@ -424,7 +431,10 @@ class VDiffEngine:
                 raise ValueError("this model is CLIP-conditioned: clip_embed is required")
             mod = self._mapping(t, clip_embed)                 # no gradient flows to the conditioning: it only scales / shifts
         planes = torch.empty((n, 16), dtype=torch.float32, device=dev)
-        call("pmi_fourier_features", ptr(t), ptr(self.tw), ptr(planes), n, 8)
+        tf = t
+        if self.spec.get("t_input") == "log_snr":       # wikiart_256.py:288-292
+            tf = torch.log(torch.cos(t * (torch.pi / 2)) ** 2 / torch.sin(t * (torch.pi / 2)) ** 2).contiguous()
+        call("pmi_fourier_features", ptr(tf), ptr(self.tw), ptr(planes), n, 8)
         x = torch.empty((n, hh, ww, 24), dtype=_hip.TORCH_DTYPE[dt], device=dev)
         call("pmi_prep_input", ptr(images), ptr(planes), 16, ptr(x), n, hh, ww, 24, dt)
         tape = []
@@ -478,21 +488,30 @@ class VDiffEngine:
         return outs[0], outs[1]
 
     def _attn_back(self, rec, g, sd):
-        _, l, p, x, aws, lse, a = rec
+        _, l, p, x, saved = rec
         dt = self.dt
         n, hh, ww, c = x.shape
-        t, heads = hh * ww, c // 64
+        d = self.spec.get("head_dim", 64)
+        t, heads = hh * ww, c // d
         g2 = g.reshape(n * t, c)
         da = ops.igemm(g2, self._wt(p + ".outT", sd[p + ".out_proj.weight"]))
-        tp32 = (t + 31) // 32 * 32
-        bws = torch.empty((2, n * heads, tp32, 64), dtype=x.dtype, device=x.device)
-        delta = torch.empty((n * heads, tp32), dtype=torch.float32, device=x.device)
-        dqkv = torch.empty((n * t, 3 * c), dtype=x.dtype, device=x.device)
-        call("pmi_vit_attn_bwd", ptr(aws), ptr(lse), ptr(a), ptr(da), ptr(bws), ptr(delta), ptr(dqkv), n, t, heads, 64.0 ** -0.5, dt)
+        if d == 64:
+            aws, lse, a = saved
+            tp32 = (t + 31) // 32 * 32
+            bws = torch.empty((2, n * heads, tp32, 64), dtype=x.dtype, device=x.device)
+            delta = torch.empty((n * heads, tp32), dtype=torch.float32, device=x.device)
+            dqkv = torch.empty((n * t, 3 * c), dtype=x.dtype, device=x.device)
+            call("pmi_vit_attn_bwd", ptr(aws), ptr(lse), ptr(a), ptr(da), ptr(bws), ptr(delta), ptr(dqkv), n, t, heads, 64.0 ** -0.5, dt)
+        else:
+            qkv, pm = saved
+            dqkv = ops.attention_backward(qkv.view(n, t, 3 * c), pm, da.view(n, t, c), heads, dt).view(n * t, 3 * c)
         dhn = ops.igemm(dqkv, self._wt(p + ".qkvT", sd[p + ".qkv_proj.weight"]))
         gx = torch.empty_like(x)
-        part = torch.empty((n, _hip.lib().pmi_gn1_bwd_partials(t, c), 4), dtype=torch.float64, device=x.device)
-        call("pmi_gn1_bwd", ptr(x), ptr(dhn), ptr(self.w[p + ".gn"][0]), 0, 0.0, ptr(g2), ptr(gx), ptr(part), n, t, c, 1e-5, dt)
+        if self.spec.get("attn_norm", True):
+            part = torch.empty((n, _hip.lib().pmi_gn1_bwd_partials(t, c), 4), dtype=torch.float64, device=x.device)
+            call("pmi_gn1_bwd", ptr(x), ptr(dhn), ptr(self.w[p + ".gn"][0]), 0, 0.0, ptr(g2), ptr(gx), ptr(part), n, t, c, 1e-5, dt)
+        else:                                        # no norm in front of the projections: the two paths just add
+            call("pmi_add16", ptr(dhn), ptr(g2), ptr(gx), gx.numel(), dt)
         return gx
 
     def _back(self, tape, g, sd, outermost=False):
@@ -506,9 +525,10 @@ class VDiffEngine:
                 g, g1 = self._res_back(rec, g, sd, first=outermost and idx == 0)
             elif kind == "skip":
                 assert g1 is not None, "a SkipBlock is always followed by the block that reads its concat"
-                gm = self._back(rec[1], g, sd)                                   # through main(x)
+                g_inner, g_x = (g1, g) if self.spec.get("skip_first") else (g, g1)
+                gm = self._back(rec[1], g_inner, sd)                             # through main(x)
                 out = torch.empty_like(gm)
-                call("pmi_add16", ptr(gm), ptr(g1), ptr(out), gm.numel(), self.dt)
+                call("pmi_add16", ptr(gm), ptr(g_x), ptr(out), gm.numel(), self.dt)
                 g, g1 = out, None
             else:
                 assert g1 is None
@@ -522,7 +542,8 @@ class VDiffEngine:
                 elif kind == "up":
                     n, h, w_, c = g.shape
                     out = torch.empty((n, h // 2, w_ // 2, c), dtype=g.dtype, device=g.device)
-                    call("pmi_upsample_bilinear2_bwd", ptr(g), ptr(out), n, h // 2, w_ // 2, c, self.dt)
+                    call("pmi_upsample_nearest2_bwd" if self.spec.get("up_mode") == "nearest" else "pmi_upsample_bilinear2_bwd",
+                         ptr(g), ptr(out), n, h // 2, w_ // 2, c, self.dt)
                     g = out
         assert g1 is None
         return g

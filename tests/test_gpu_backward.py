@@ -149,6 +149,50 @@ def test_cc12m1_full_input_gradient_vs_reference_autograd():
     assert rel <= 1.5e-1 and cos >= 0.99
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_wikiart_style_tiny_net_input_gradient(dtype):
+    """The wikiart layer set (no attention norm, non-64-channel heads through the batched-GEMM attention backward, nearest upsampling and its
+    adjoint, skip-first concat, log-SNR timestep features) on a tiny net vs autograd over the oracle."""
+    from oracle import vdiff as ov
+    from perceptor_amd.engine import vdiff
+    from perceptor_amd.utils.synth import seeded_noise, synth_state_dict
+    kw = dict(head_dim=32, attn_norm=False, up_mode="nearest", t_input="log_snr", skip_first=True)     # 32-channel heads: the batched-GEMM path, as 128 is
+    spec = vdiff.make_spec("tinyw", (3, 32, 32), [64, 128, 128], 2, 2, 4, 1, False, **kw)
+    sd = synth_state_dict(vdiff.state_dict_shapes(spec), 0, gain=0.7)
+    eng = vdiff.VDiffEngine(spec, sd, DEV, dtype)
+    ospec = dict(ov.tiny_spec(False), head_dim=32, up_mode="nearest", t_input="log_snr", skip_first=True)
+    x = seeded_noise((2, 3, 32, 32), 5)
+    t = torch.tensor([0.8, 0.3])
+    probe = seeded_noise((2, 3, 32, 32), 8)
+    xr = x.clone().requires_grad_()
+    with torch.enable_grad():
+        v_ref = ov.vdiff_forward.__wrapped__(sd, ospec, xr, t)
+        (g_ref,) = torch.autograd.grad((v_ref * probe).sum(), xr)
+    img = ((x + 1) / 2).to(DEV)
+    v, tape = eng.forward_train(img, t.to(DEV))
+    assert _rel(v.cpu(), v_ref.detach()) <= 2e-2
+    g_x = eng.backward(tape, probe.to(DEV), sd).cpu() / 2
+    rel, cos = _rel(g_x, g_ref), _cos(g_x, g_ref)
+    print(f"[parity] tiny wikiart-style v-net input gradient {dtype}: rel-L2={rel:.3e}, cos={cos:.5f}")
+    assert rel <= (1e-1 if dtype == "bf16" else 4e-2) and cos >= (0.995 if dtype == "bf16" else 0.9995)
+
+
+def test_wikiart_full_input_gradient_vs_reference_autograd():
+    from perceptor_amd import models
+    from perceptor_amd.utils.synth import seeded_noise
+    g0, g = golden("vdiff_wikiart_64"), golden("vdiff_wikiart_64_grad")
+    m = models.VelocityDiffusion("wikiart", dtype="bf16", weight_gain=0.6).to(DEV)
+    img = ((g0["x"] + 1) / 2).to(DEV).requires_grad_()
+    probe = seeded_noise((1, 3, 64, 64), 48).to(DEV)
+    with torch.enable_grad():
+        v = m.velocities(img, g["t"].to(DEV))
+        (v * probe).sum().backward()
+    g_x = img.grad.cpu() / 2
+    rel, cos = _rel(g_x, g["g"]), _cos(g_x, g["g"])
+    print(f"[parity] wikiart@64 input gradient bf16 vs reference autograd: rel-L2={rel:.3e}, cos={cos:.5f}")
+    assert rel <= 1.5e-1 and cos >= 0.99
+
+
 def test_guided_resample_matches_autograd_chain_over_the_oracle():
     """losses.VelocityDiffusion.guided_resample_ (reference losses/velocity_diffusion.py:33-61) on a tiny net: the noise gradient
     against autograd over diffuse -> oracle UNet -> denoised_images, then the update rule with the device noise injected."""
