@@ -427,9 +427,22 @@ void pmi_conv3x3_prefer_256(int v) { g_prefer0 = v; }
 // Returns the tile config the halo kernel runs for this shape (0: 8x32 px x 256 ch / 8 waves, 1: 16x32 x 128 / 8 waves,
 // 2: 8x32 x 128 / 4 waves x 2 workgroups per CU, 3: 8x32 px x <= 32 channels) or -1 if the shape needs the generic kernel.
 extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
-  if (a->taps != 9 || a->stride != 1 || a->batch > 1 || a->split_out || a->split_in) return -1;
+  if (a->taps != 9 || a->stride != 1 || a->batch > 1) return -1;
   const int Cin = a->C0 + a->C1;
   if ((Cin % 64) || (a->C0 % 64) || (a->W % 32) || (a->H % 8)) return -1;
+  if (a->split_out || a->split_in) {
+    // precise mode (hi + lo f16 pairs): the weights-direct kernel's 16x16x32 configs only -- its input is an ordinary K dimension of 2C
+    // physical channels against duplicated weights, its split epilogue writes [C/32][hi | lo]; no fused prologue / statistics there
+    if (!a->Bf || !g_wd || !g_wd_mf16 || a->split_out != 32 || !a->split_in || a->out_f32 || (a->R && a->res_f32) || a->pro_a || a->stats ||
+        (a->N % 128))
+      return -1;
+    const int t8s = a->M / (a->H * a->W) * (a->H / 8) * (a->W / 32);
+    if (g_force_cfg == 6 || g_force_cfg == 7) return ((a->N % 256) == 0 || g_force_cfg == 7) ? g_force_cfg : -1;
+    if (g_force_cfg >= 0) return -1;
+    if ((a->N % 256) == 0 && t8s * (a->N / 256) >= 192) return 6;
+    if (g_wd128 && t8s * (a->N / 128) >= 128) return 7;
+    return -1;
+  }
   // config 3: at most 32 output channels (the UNet's last conv, 128 -> 6): one MFMA block column per wave
   if (a->N <= 32 && (a->N % 4) == 0 && !a->stats && !a->res_up && a->M / (a->H * a->W) * (a->H / 8) * (a->W / 32) >= 256) return 3;
   if ((a->N % 128) || a->out_f32 || (a->R && a->res_f32)) return -1;

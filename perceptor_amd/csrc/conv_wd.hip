@@ -40,7 +40,9 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // NWN waves x 32 channels = the tile's output channels; CK = input channels per staged chunk.  (8, 64): one 8-wave workgroup per CU,
 // 256-channel tiles (configs 4 / 6).  (4, 32): 128-channel tiles for the 128-channel layers, 4 waves and ~75 KB of LDS, so TWO
 // workgroups share a CU and one's prologue / epilogue runs under the other's main loop (config 7; 16x16x32 MFMA only).
-template <typename T, int PRO, bool MF16, int NWN = 8, int CK = 64>
+// SPL: precise mode (dtype 2): the output (and a residual) are hi + lo f16 pairs, [C/32][hi 32 | lo 32] per pixel (common.h: F16X2); the
+// input needs nothing special -- its 2C physical channels are an ordinary K dimension against duplicated weights.
+template <typename T, int PRO, bool MF16, int NWN = 8, int CK = 64, bool SPL = false>
 __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm_args a) {
   constexpr int NW = NWN, NT = NW * 64;
   constexpr int KS = MF16 ? CK / 32 : CK / 16;         // k-steps (one MFMA deep) per chunk
@@ -291,6 +293,53 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
 
   CSTAMP(1);
   STAMP(2);
+  if constexpr (SPL) {
+    // ---- precise-mode epilogue: straight from the accumulators.  A lane holds 4 consecutive channels of a pixel: 8 bytes of high parts
+    // and 8 bytes of low parts, the four quarter-waves of a 16-channel block complete two 32-byte runs per pixel.  No statistics here
+    // (pmi_igemm_stats_rows reports none for split outputs: the next GroupNorm runs its own pass), a split residual is added in fp32.
+    static_assert(MF16 && PRO == 0, "precise mode: 16x16x32 tiles without a fused prologue");
+    const int G = a.split_out;                           // 32 (Cout is a multiple of 128)
+    const float* const nbp = a.nbias ? a.nbias + (int64_t)img * (a.ldnb ? a.ldnb : a.N) : nullptr;
+    act_switch(a.act, [&](auto act_c) __attribute__((always_inline)) {
+      constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const int n = n0 + wn * 32 + cb * 16 + 4 * (lane >> 4);
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) b = *(const float4*)(a.bias + n);
+        if (nbp) { const float4 q = *(const float4*)(nbp + n); b.x += q.x; b.y += q.y; b.z += q.z; b.w += q.w; }
+        const int po = split_off(n, G);                  // offset of the high parts inside a pixel row; low parts at + G
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int sx = 0; sx < 2; ++sx) {
+            const f32x4 c = acc4[i][sx][cb];
+            float v[4] = {c[0] * a.alpha + b.x, c[1] * a.alpha + b.y, c[2] * a.alpha + b.z, c[3] * a.alpha + b.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], ACT);
+            const int y = y0 + i, x = x0 + sx * 16 + (lane & 15);
+            if (a.R) {
+              const int64_t rr = a.res_up ? (((int64_t)img * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.ldr
+                                          : (((int64_t)img * a.H + y) * a.W + x) * a.ldr;
+              const uint2 rh = *(const uint2*)((const u16*)a.R + rr + po), rl = *(const uint2*)((const u16*)a.R + rr + po + G);
+              v[0] += F16::to_f((u16)(rh.x & 0xffff)) + F16::to_f((u16)(rl.x & 0xffff));
+              v[1] += F16::to_f((u16)(rh.x >> 16)) + F16::to_f((u16)(rl.x >> 16));
+              v[2] += F16::to_f((u16)(rh.y & 0xffff)) + F16::to_f((u16)(rl.y & 0xffff));
+              v[3] += F16::to_f((u16)(rh.y >> 16)) + F16::to_f((u16)(rl.y >> 16));
+            }
+            u16 h[4];
+            float l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h[e] = F16::from_f(v[e]); l[e] = v[e] - F16::to_f(h[e]); }
+            u16* const o = (u16*)a.D + (((int64_t)img * a.H + y) * a.W + x) * a.ldd + po;
+            *(uint2*)o = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+            *(uint2*)(o + G) = pack4<F16>(l[0], l[1], l[2], l[3]);
+          }
+      }
+    });
+    STAMP(3);
+    return;
+  }
   // ---- epilogue: the whole tile goes through LDS once and leaves as full pixel rows (BN x 2 B contiguous) ----
   char* const stg = smem;
   float* const stat = (float*)(smem + NPX * SROW);     // [NW][BN][2] (sum, sumsq) partials per write-out wave, summed in a fixed order
@@ -421,6 +470,16 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
 template <typename T, int PRO>
 int launch_p(const pmi_igemm_args& a, hipStream_t s, int cfg) {
   const int nimg = a.M / (a.H * a.W);
+  if constexpr (PRO == 0) {
+    if (a.split_out) {                                 // precise mode (hi + lo output): configs 6 / 7 only
+      if (cfg == 7) hipLaunchKernelGGL((conv3x3_wd_kernel<T, 0, true, 4, 32, true>), dim3(nimg * (a.H / 8) * (a.W / 32) * (a.N / 128)), dim3(256), 0, s, a);
+      else if (cfg == 6) hipLaunchKernelGGL((conv3x3_wd_kernel<T, 0, true, 8, 64, true>), dim3(nimg * (a.H / 8) * (a.W / 32) * (a.N / 256)), dim3(512), 0, s, a);
+      else return PMI_ERR_ARG;
+      PMI_CHECK_LAUNCH();
+      return PMI_OK;
+    }
+  }
+  if (a.split_out) return PMI_ERR_ARG;
   if (cfg == 7) {                                      // 128-channel tiles, two 4-wave workgroups per CU
     hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, true, 4, 32>), dim3(nimg * (a.H / 8) * (a.W / 32) * (a.N / 128)), dim3(256), 0, s, a);
     PMI_CHECK_LAUNCH();

@@ -572,7 +572,7 @@ extern "C" int pmi_igemm_splitk(const pmi_igemm_args* a) {
 }
 
 extern "C" int pmi_igemm_stats_rows(const pmi_igemm_args* a) {
-  if (a->batch > 1 || a->splitk > 1) return 0;
+  if (a->batch > 1 || a->splitk > 1 || a->split_out) return 0;          // (split outputs: the generic fast epilogue and the wd kernel take none)
   const int halo = g_allow_halo ? pmi_conv3x3_halo_config(a) : -1;
   if (halo == 3) return 0;                                             // few-output-channel config: no statistics epilogue
   if (halo >= 0) return (a->H / (halo == 1 ? 16 : 8)) * (a->W / 32);   // configs 0, 2: 8-row tiles
