@@ -236,6 +236,12 @@ int pmi_layernorm_bwd(const float* dy, const float* x, const float* gamma, const
                       float* g32, void* g16, int M, int D, int dy_ld, int row_stride, int dtype, pmi_stream_t s);
 /* softmax over the first T columns of fp32 scores * scale -> 16-bit probabilities (zero padded to ld_out) */
 int pmi_softmax_fwd(const float* S, void* P, int rows, int T, int ld_in, int ld_out, float scale, int dtype, pmi_stream_t s);
+/* CLIP text tower (open_clip text transformer reached through models/open_clip.py:99-107; transformers CLIPTextModel through
+ * models/stable_diffusion/stable_diffusion.py:295-323): causal variant of pmi_softmax_fwd -- rows = batch*heads*T, query row r
+ * sees keys 0..(r mod T) -- plus x[n][t][:] = tok[ids[n][t]][:] + pos[t][:] (pos may be NULL) and a row gather (the EOT token's row). */
+int pmi_softmax_causal_fwd(const float* S, void* P, int rows, int T, int ld_in, int ld_out, float scale, int dtype, pmi_stream_t s);
+int pmi_embed_tokens(const int64_t* ids, const float* tok, const float* pos, float* x, int N, int T, int D, int vocab, pmi_stream_t s);
+int pmi_gather_rows(const float* src, const int64_t* idx, float* dst, int R, int D, int ld, int64_t src_rows, pmi_stream_t s);
 int pmi_softmax_bwd(const float* dP, const void* P, void* dS, int rows, int T, int ld_dp, int ld_p, float scale, int dtype, pmi_stream_t s);
 /* in[b][R][Cc] (row stride ld_in, batch offset (b/batch_inner)*sI_o + (b%batch_inner)*sI_i) -> out[b][Cc][Rp], Rp = R rounded up to 8 */
 int pmi_transpose_16(const void* in, void* out, int R, int Cc, int ld_in, int64_t sI_o, int64_t sI_i, int batch_inner, int batch, pmi_stream_t s);

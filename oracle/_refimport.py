@@ -86,6 +86,7 @@ def install() -> None:
     _shell("perceptor.models.guided_diffusion", os.path.join(p, "models", "guided_diffusion"))
     _shell("perceptor.models.velocity_diffusion", os.path.join(p, "models", "velocity_diffusion"))
     _shell("perceptor.models.ruclip", os.path.join(p, "models", "ruclip"))
+    _shell("perceptor.models.slip", os.path.join(p, "models", "slip"))      # only its tokenizer.py is loaded (gen_tokenizer)
     _shell("perceptor.transforms", os.path.join(p, "transforms"))
     _shell("perceptor.transforms.resize", os.path.join(p, "transforms", "resize"))
     utils = _shell("perceptor.utils", os.path.join(p, "utils"))

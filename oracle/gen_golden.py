@@ -348,6 +348,94 @@ def gen_clip_hf():
              grad_sub=g[:, :, ::4, ::4].contiguous(), grad_mom=moments(g))
 
 
+def _text_ids(n, t, vocab, seed):
+    """Random prompts: BOS-like id, words, one EOT (= vocab - 1, the largest id) at a per-row position, zero padding behind it."""
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.zeros((n, t), dtype=torch.int64)
+    for i in range(n):
+        L = int(torch.randint(2, t, (1,), generator=g))       # position of the EOT token
+        ids[i, 0] = vocab - 2
+        ids[i, 1:L] = torch.randint(1, vocab - 2, (L - 1,), generator=g)
+        ids[i, L] = vocab - 1
+    return ids
+
+
+def _hf_text_tower(cfg, sd, quick_gelu):
+    """transformers' CLIPTextModelWithProjection from a config object (no download), loaded with the open_clip-named weights."""
+    hidden = {k: sys.modules.pop(k) for k in [k for k in sys.modules if k == "torchvision" or k.startswith("torchvision.")]}
+    try:
+        from transformers import CLIPTextConfig, CLIPTextModelWithProjection
+    finally:
+        sys.modules.update(hidden)
+    ctx, vocab, width, layers, heads, odim = cfg
+    c = CLIPTextConfig(vocab_size=vocab, hidden_size=width, intermediate_size=4 * width, num_hidden_layers=layers, num_attention_heads=heads,
+                       max_position_embeddings=ctx, projection_dim=odim, hidden_act="quick_gelu" if quick_gelu else "gelu",
+                       layer_norm_eps=1e-5, attention_dropout=0.0, eos_token_id=vocab - 1, bos_token_id=vocab - 2, pad_token_id=0)
+    c._attn_implementation = "eager"
+    m = CLIPTextModelWithProjection(c).eval()
+    hf = {"text_model.embeddings.token_embedding.weight": sd["token_embedding.weight"],
+          "text_model.embeddings.position_embedding.weight": sd["positional_embedding"],
+          "text_model.final_layer_norm.weight": sd["ln_final.weight"], "text_model.final_layer_norm.bias": sd["ln_final.bias"],
+          "text_projection.weight": sd["text_projection"].t().contiguous()}
+    for i in range(layers):
+        a, b = f"transformer.resblocks.{i}.", f"text_model.encoder.layers.{i}."
+        wq, wk, wv = sd[a + "attn.in_proj_weight"].chunk(3, dim=0)
+        bq, bk, bv = sd[a + "attn.in_proj_bias"].chunk(3, dim=0)
+        for nm, w_, b_ in (("q", wq, bq), ("k", wk, bk), ("v", wv, bv)):
+            hf[b + f"self_attn.{nm}_proj.weight"], hf[b + f"self_attn.{nm}_proj.bias"] = w_, b_
+        for src, dst in (("attn.out_proj", "self_attn.out_proj"), ("ln_1", "layer_norm1"), ("ln_2", "layer_norm2"),
+                         ("mlp.c_fc", "mlp.fc1"), ("mlp.c_proj", "mlp.fc2")):
+            hf[b + dst + ".weight"], hf[b + dst + ".bias"] = sd[a + src + ".weight"], sd[a + src + ".bias"]
+    missing, unexpected = m.load_state_dict(hf, strict=False)
+    assert not unexpected and all("position_ids" in k for k in missing), (missing, unexpected)
+    return m
+
+
+def gen_clip_text():
+    """CLIP text tower: (i) the reference's in-tree ruclip CLIP.encode_text (ruclip/model.py:204-228, QuickGELU) on a tiny config,
+    (ii) transformers' CLIPTextModelWithProjection on a tiny exact-GELU config and on the ViT-L/14 text tower (QuickGELU: the
+    encoder StableDiffusion conditions on, stable_diffusion.py:298-301) -- all with the name-keyed synthetic weights."""
+    from oracle.clip_text import TEXT_CONFIGS, text_state_dict_shapes
+    from perceptor_amd.utils.synth import synth_state_dict
+    ru = R.ref("models.ruclip.model")
+    cfg = TEXT_CONFIGS["tiny"]
+    ctx, vocab, width, layers, heads, odim = cfg
+    m = ru.CLIP(embed_dim=odim, image_resolution=32, vision_layers=1, vision_width=64, vision_patch_size=16, context_length=ctx,
+                vocab_size=vocab, transformer_width=width, transformer_heads=heads, transformer_layers=layers, eos_id=vocab - 1).eval()
+    sd = synth_state_dict(text_state_dict_shapes(cfg), 0)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.startswith("visual.") or k == "logit_scale" for k in missing), (missing, unexpected)
+    ids = _text_ids(3, ctx, vocab, 61)
+    with torch.no_grad():
+        save("clip_text_ruclip_tiny", ids=ids, pooled=m.encode_text(ids))
+    for tag, n, t, quick in (("tiny-wide", 3, 24, False), ("ViT-L-14", 2, 77, True)):
+        cfg = TEXT_CONFIGS[tag]
+        sd = synth_state_dict(text_state_dict_shapes(cfg), 0)
+        m = _hf_text_tower(cfg, sd, quick)
+        ids = _text_ids(n, t, cfg[1], 62)
+        with torch.no_grad():
+            o = m(input_ids=ids)
+        save(f"clip_text_hf_{tag}_{'quickgelu' if quick else 'gelu'}", ids=ids, hidden=o.last_hidden_state, pooled=o.text_embeds)
+
+
+TOKENIZER_PROMPTS = [
+    "a photograph of a playful cat", "painting of a dog", "", "  Hello,   World!  it's 2023 -- don't panic...",
+    "An astronaut riding a horse on Mars; 4k, trending on artstation (highly detailed)", "fish &amp; chips &lt;3 #tasty @home 100% / 50$",
+    "supercalifragilisticexpialidocious antidisestablishmentarianism", "the quick brown fox jumps over the lazy dog " * 12,
+]
+
+
+def gen_tokenizer():
+    """Token ids of the reference's own CLIP tokenizer (models/slip/tokenizer.py:70-165, reading the merge list that lies next to it)
+    for ASCII prompts.  The module imports ftfy (absent here): a stand-in whose fix_text is the identity is registered for the import
+    -- the identity is what ftfy.fix_text returns for well-formed ASCII text, so no arithmetic of the path is replaced."""
+    import types
+    sys.modules.setdefault("ftfy", types.SimpleNamespace(fix_text=lambda t: t))
+    tk = R.ref("models.slip.tokenizer").SimpleTokenizer()
+    ids = torch.stack([tk(p) for p in TOKENIZER_PROMPTS])
+    save("clip_tokenizer", ids=ids, lengths=np.array([len(tk.encode(p)) for p in TOKENIZER_PROMPTS]))
+
+
 if __name__ == "__main__" and len(sys.argv) > 1:
     for name in sys.argv[1:]:
         globals()["gen_" + name]()

@@ -108,6 +108,9 @@ _PROTOS = {
     "pmi_layernorm_fwd": ([_P, _I, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],),
     "pmi_layernorm_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],),
     "pmi_softmax_fwd": ([_P, _P, _I, _I, _I, _I, _F, _I, _P],),
+    "pmi_softmax_causal_fwd": ([_P, _P, _I, _I, _I, _I, _F, _I, _P],),
+    "pmi_embed_tokens": ([_P, _P, _P, _P, _I, _I, _I, _I, _P],),
+    "pmi_gather_rows": ([_P, _P, _P, _I, _I, _I, _L, _P],),
     "pmi_softmax_bwd": ([_P, _P, _P, _I, _I, _I, _I, _F, _I, _P],),
     "pmi_transpose_16": ([_P, _P, _I, _I, _I, _L, _L, _I, _I, _P],),
     "pmi_act_bwd": ([_P, _P, _P, _L, _I, _I, _P],),

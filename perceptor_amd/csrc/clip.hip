@@ -102,10 +102,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 // ---- row softmax over the first T columns of fp32 scores; 16-bit probabilities, zero padding -----
 template <typename TT>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, u16* __restrict__ P, int rows, int T,
-                                                          int ld_in, int ld_out, float scale) {
+                                                          int ld_in, int ld_out, float scale, int causal_t) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* sr = S + (int64_t)row * ld_in;
+  if (causal_t > 0) T = min(T, row % causal_t + 1);   // query i of a causal_t-token sequence sees keys 0..i
   float mx = -1e30f;
   for (int c = lane; c < T; c += 64) mx = fmaxf(mx, sr[c] * scale);
   mx = wave_max(mx);
@@ -294,6 +295,30 @@ __global__ __launch_bounds__(256) void spherical_loss_kernel(const float* __rest
   if (tid == 0) *loss = ltot * mult * inv_count;
 }
 
+// ---- CLIP text tower: x[n][t][:] = token_embedding[ids[n][t]] + positional_embedding[t] ------------
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tok,
+                                                           const float* __restrict__ pos, float* __restrict__ x, int64_t total, int T, int D, int vocab) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int d = (int)(i % D);
+    const int64_t r = i / D;
+    const int t = (int)(r % T);
+    int64_t id = ids[r];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);      // the host validates ids; never read out of the table
+    x[i] = tok[id * D + d] + (pos ? pos[(int64_t)t * D + d] : 0.f);
+  }
+}
+
+// dst[r][:] = src[idx[r]][:] (fp32 rows)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, float* __restrict__ dst,
+                                                          int R, int D, int ld, int64_t src_rows) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)R * D; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / D), d = (int)(i % D);
+    int64_t j = idx[r];
+    j = j < 0 ? 0 : (j >= src_rows ? src_rows - 1 : j);
+    dst[i] = src[j * ld + d];
+  }
+}
+
 }  // namespace
 
 #define ST ((hipStream_t)s)
@@ -323,7 +348,27 @@ extern "C" int pmi_layernorm_bwd(const float* dy, const float* x, const float* g
 extern "C" int pmi_softmax_fwd(const float* S, void* P, int rows, int T, int ld_in, int ld_out, float scale, int dtype, pmi_stream_t s) {
   if (!S || !P || rows <= 0 || T <= 0 || ld_in < T || ld_out < T) return PMI_ERR_ARG;
   dim3 grid((rows + 3) / 4), block(256);
-  BY_DTYPE(softmax_fwd_kernel, S, (u16*)P, rows, T, ld_in, ld_out, scale);
+  BY_DTYPE(softmax_fwd_kernel, S, (u16*)P, rows, T, ld_in, ld_out, scale, 0);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_softmax_causal_fwd(const float* S, void* P, int rows, int T, int ld_in, int ld_out, float scale, int dtype, pmi_stream_t s) {
+  if (!S || !P || rows <= 0 || T <= 0 || rows % T || ld_in < T || ld_out < T) return PMI_ERR_ARG;
+  dim3 grid((rows + 3) / 4), block(256);
+  BY_DTYPE(softmax_fwd_kernel, S, (u16*)P, rows, T, ld_in, ld_out, scale, T);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_embed_tokens(const int64_t* ids, const float* tok, const float* pos, float* x, int N, int T, int D, int vocab, pmi_stream_t s) {
+  if (!ids || !tok || !x || N <= 0 || T <= 0 || D <= 0 || vocab <= 0) return PMI_ERR_ARG;
+  const int64_t total = (int64_t)N * T * D;
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3(grid_for(total)), dim3(256), 0, ST, ids, tok, pos, x, total, T, D, vocab);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_gather_rows(const float* src, const int64_t* idx, float* dst, int R, int D, int ld, int64_t src_rows, pmi_stream_t s) {
+  if (!src || !idx || !dst || R <= 0 || D <= 0 || ld < D || src_rows <= 0) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)R * D)), dim3(256), 0, ST, src, idx, dst, R, D, ld, src_rows);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }

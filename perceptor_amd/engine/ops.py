@@ -356,13 +356,16 @@ def upsample_nearest2(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def attention(qkv: torch.Tensor, heads: int, order: int, dt: int) -> torch.Tensor:
+def attention(qkv: torch.Tensor, heads: int, order: int, dt: int, causal: bool = False) -> torch.Tensor:
     """Self-attention over tokens.  qkv: [N, T, 3C] 16-bit -> [N, T, C].
+    causal: query i sees keys 0..i (the CLIP text tower's mask, ruclip/model.py:181-185); runs the batched-GEMM path.
 
     order 0: channels = (head, {q,k,v}, d) (unet.py:332-348); order 1: ({q,k,v}, head, d).
     Head dim 64 runs the fused flash kernel; other head dims use batched MFMA GEMMs + softmax.
     """
     if dt == DT_F16X2:
+        if causal:
+            raise NotImplementedError("causal attention has no precise-mode path")
         return attention_precise(qkv, heads, order)
     n, t, c3 = qkv.shape
     c = c3 // 3
@@ -370,7 +373,7 @@ def attention(qkv: torch.Tensor, heads: int, order: int, dt: int) -> torch.Tenso
     dev = qkv.device
     out = _empty((n, t, c), qkv.dtype, dev)
     scale = float(d) ** -0.5
-    if d == 64:
+    if d == 64 and not causal:
         tp = (t + 31) // 32 * 32
         q = _empty((n * heads, tp, 64), qkv.dtype, dev)
         k = _empty((n * heads, tp, 64), qkv.dtype, dev)
@@ -388,7 +391,7 @@ def attention(qkv: torch.Tensor, heads: int, order: int, dt: int) -> torch.Tenso
     bgemm(qkv, qkv, s, M=t, N=t, K=d, lda=c3, ldb=c3, ldd=tp, batch=n * heads, batch_inner=heads,
           sA=(t * c3, hs), sB=(t * c3, hs), sD=(heads * t * tp, t * tp), dt=dt, a_off=qo, b_off=ko)
     p = _empty((n * heads, t, tp), qkv.dtype, dev)
-    call("pmi_softmax_fwd", ptr(s), ptr(p), n * heads * t, t, tp, tp, scale, dt)
+    call("pmi_softmax_causal_fwd" if causal else "pmi_softmax_fwd", ptr(s), ptr(p), n * heads * t, t, tp, tp, scale, dt)
     vt = _empty((n * heads, d, tp), qkv.dtype, dev)
     call("pmi_transpose_16", qkv.data_ptr() + vo * qkv.element_size(), ptr(vt), t, d, c3, t * c3, hs, heads, n * heads)
     bgemm(p, vt, out, M=t, N=d, K=tp, lda=tp, ldb=tp, ldd=c, batch=n * heads, batch_inner=heads,

@@ -4,9 +4,13 @@ Call surface of perceptor/models/open_clip.py:12-140 and perceptor/models/clip.p
 tower runs in perceptor_amd.engine.vit.VitEngine (HIP); pre-processing is the reference's:
 resize (ResizeRight lanczos3/bicubic) -> Normalize(mean, std) -> tower -> F.normalize.
 
+The text tower (``encode_texts``, models/open_clip.py:99-107) runs in perceptor_amd.engine.text.TextEngine behind
+perceptor_amd.utils.tokenizer.ClipTokenizer; the tokenizer's merge list is data that ships with CLIP checkpoints
+(``bpe_path=`` / ``PERCEPTOR_AMD_BPE``), token ids can also be passed directly (``encode_tokens``).
+
 Not available here (SURVEY.md §8f-4, stated loudly instead of faked): pretrained weights (no network;
 ``weights="synthetic"`` gives name-keyed deterministic weights, or pass ``checkpoint=`` with an
-open_clip ``visual.*`` state dict), the text tower / tokenizer (``encode_texts``) and ResNet towers.
+open_clip state dict: ``visual.*`` and, for the text side, the root-level text-tower tensors) and ResNet towers.
 """
 from __future__ import annotations
 
@@ -16,6 +20,7 @@ import torch
 
 from .. import _hip
 from .._hip import call, ptr
+from ..engine import text as text_engine
 from ..engine import vit
 from ..utils.param_tree import ParamTree
 from ..utils.synth import synth_state_dict
@@ -62,7 +67,8 @@ class _EncodeImages(torch.autograd.Function):
 
 class OpenCLIP(torch.nn.Module):
     def __init__(self, architecture="ViT-H-14", weights="laion2b_s32b_b79k", precision=None, *, checkpoint: Optional[str] = None,
-                 seed: int = 0, quick_gelu: Optional[bool] = None, config: Optional[tuple] = None):
+                 seed: int = 0, quick_gelu: Optional[bool] = None, config: Optional[tuple] = None, text_config: Optional[tuple] = None,
+                 bpe_path: Optional[str] = None):
         """
         Args:
             architecture (str): name of the clip model
@@ -92,22 +98,43 @@ class OpenCLIP(torch.nn.Module):
                           "stream, LayerNorm and softmax); embedding rel-L2 error vs fp32 ~4e-3 (tests/test_gpu_clip.py)", RuntimeWarning, stacklevel=2)
         self.precision = {None: "bf16", "fp16": "f16", "f16": "f16", "bf16": "bf16", "fp32": "bf16"}[precision]
         shapes = vit.vit_state_dict_shapes(self.cfg)
+        # text tower (context, vocab, width, layers, heads, out_dim): open_clip's config of the architecture, or text_config=
+        self.text_cfg = tuple(text_config) if text_config is not None else (text_engine.TEXT_CONFIGS.get(base) if config is None else None)
+        tshapes = text_engine.text_state_dict_shapes(self.text_cfg) if self.text_cfg is not None else {}
         if checkpoint is not None:
-            sd = torch.load(checkpoint, map_location="cpu", weights_only=True)
-            sd = {k[len("visual."):] if k.startswith("visual.") else k: v.float() for k, v in sd.items()}
+            raw = torch.load(checkpoint, map_location="cpu", weights_only=True)
+            sd = {k[len("visual."):]: v.float() for k, v in raw.items() if k.startswith("visual.")} or {k: v.float() for k, v in raw.items()}
             sd = {k: v for k, v in sd.items() if k in shapes}
             if set(sd) != set(shapes):
                 raise RuntimeError("checkpoint does not contain the visual tower's tensors")
+            tsd = {k: v.float() for k, v in raw.items() if k in tshapes}
+            if set(tsd) != set(tshapes):          # a visual-only file: the model has no text side
+                tsd, self.text_cfg = {}, None
         else:
             sd = synth_state_dict(shapes, seed)
-        # the reference holds the open_clip model as self.model with the image tower under "visual." (models/open_clip.py:65-76)
-        self.model = ParamTree({"visual." + k: v for k, v in sd.items()})
+            tsd = synth_state_dict(tshapes, seed) if tshapes else {}
+        # the reference holds the open_clip model as self.model: image tower under "visual.", text tower at its root (models/open_clip.py:65-76)
+        self.model = ParamTree({**{"visual." + k: v for k, v in sd.items()}, **tsd})
         self._engine: Optional[vit.VitEngine] = None
-        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_engine", None))
+        self._text_engine: Optional[text_engine.TextEngine] = None
+        self._tokenizer, self._bpe_path = None, bpe_path
+        self.register_load_state_dict_post_hook(lambda module, incompatible: (setattr(module, "_engine", None), setattr(module, "_text_engine", None)))
         self.output_dim = self.cfg[5]
 
     def visual_state_dict(self):
-        return {k[len("visual."):]: v for k, v in self.model.state_dict().items()}
+        return {k[len("visual."):]: v for k, v in self.model.state_dict().items() if k.startswith("visual.")}
+
+    @property
+    def text(self) -> text_engine.TextEngine:
+        """The text tower's engine, packed on first use (prompts are encoded once per run)."""
+        if self.text_cfg is None:
+            raise RuntimeError("this OpenCLIP holds no text tower (visual-only checkpoint or a custom config without text_config=)")
+        if self.device.type != "cuda":
+            raise RuntimeError("OpenCLIP needs a HIP device: call .to('cuda') first (perceptor_amd has no CPU fallback)")
+        if self._text_engine is None:
+            sd = {k: v for k, v in self.model.state_dict().items() if not k.startswith("visual.")}
+            self._text_engine = text_engine.TextEngine(self.text_cfg, sd, self.device, self.precision, self.quick_gelu)
+        return self._text_engine
 
     @property
     def engine(self) -> Optional[vit.VitEngine]:
@@ -117,6 +144,7 @@ class OpenCLIP(torch.nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._engine = None
+        self._text_engine = None
         return super()._apply(fn, *a, **k)
 
     def to(self, *args, **kwargs):
@@ -137,9 +165,26 @@ class OpenCLIP(torch.nn.Module):
             raise RuntimeError("OpenCLIP needs a HIP device: call .to('cuda') first (perceptor_amd has no CPU fallback)")
         return self.engine
 
+    def tokenize(self, text_prompts) -> torch.Tensor:
+        """open_clip.tokenize (models/open_clip.py:101-103): int64 [N, context], zero padded."""
+        if self._tokenizer is None:
+            from ..utils.tokenizer import ClipTokenizer
+            self._tokenizer = ClipTokenizer(self._bpe_path)
+        ctx = self.text_cfg[0] if self.text_cfg is not None else 77
+        return self._tokenizer(text_prompts, context_length=ctx)
+
+    def encode_tokens(self, token_ids: torch.Tensor, normalize=True):
+        """The text tower on token ids [N, T] (int64): what encode_texts runs behind the tokenizer."""
+        _, pooled = self.text.forward(token_ids)
+        if normalize:
+            out = torch.empty_like(pooled)
+            pooled = pooled.contiguous()
+            call("pmi_l2norm_rows", ptr(pooled), ptr(out), pooled.shape[0], pooled.shape[1], 1.0)
+            return out
+        return pooled
+
     def encode_texts(self, text_prompts, normalize=True):
-        raise NotImplementedError("the CLIP text tower/tokenizer is not part of the HIP hot path yet (SURVEY.md §8f-4); "
-                                  "pass precomputed text embeddings to add_encodings_")
+        return self.encode_tokens(self.tokenize(text_prompts), normalize)
 
     def encode_images(self, images, normalize=True):
         self._need_engine()

@@ -1,5 +1,7 @@
 """CPU: host-side logic of the drop-in classes (schedules, shapes, packing, resize tables, error behaviour)
 against the reference's golden vectors.  No HIP compute."""
+import os
+
 import pytest
 import torch
 
@@ -152,3 +154,38 @@ def test_velocity_diffusion_and_clip_state_dicts():
     c = models.OpenCLIP("tiny-test", "synthetic", config=(32, 8, 64, 2, 1, 32))
     assert set(c.state_dict()) == {"model.visual." + k for k in vit.vit_state_dict_shapes((32, 8, 64, 2, 1, 32))}
     assert c.device.type == "cpu" and c.engine is None
+
+
+REF_BPE = "/root/reference/perceptor/models/slip/bpe_simple_vocab_16e6.txt.gz"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BPE), reason="the CLIP merge list is data that is not part of this repository (build container only)")
+def test_clip_tokenizer_matches_reference_ids():
+    """perceptor_amd.utils.tokenizer against ids the reference's own tokenizer produced (oracle/gen_golden.py: gen_tokenizer), reading the
+    merge list (data, 48 894 merges) from where it lies in the reference tree; skipped where that tree is absent."""
+    from oracle.gen_golden import TOKENIZER_PROMPTS
+    from perceptor_amd.utils.tokenizer import ClipTokenizer
+    g = golden("clip_tokenizer")
+    tk = ClipTokenizer(REF_BPE)
+    assert tk.vocab_size == 49408 and (tk.sot, tk.eot) == (49406, 49407)
+    for i, p in enumerate(TOKENIZER_PROMPTS):
+        assert len(tk.encode(p)) == int(g["lengths"][i])
+    ids = tk(TOKENIZER_PROMPTS)
+    # the reference tokenizer cuts an over-long prompt without restoring the end token (slip/tokenizer.py:163-165); open_clip.tokenize,
+    # which models/open_clip.py:102 calls, sets the last id to the end token: identical everywhere else
+    long_rows = g["lengths"] + 2 > 77
+    assert torch.equal(ids[~long_rows], g["ids"][~long_rows])
+    assert torch.equal(ids[long_rows][:, :-1], g["ids"][long_rows][:, :-1]) and bool((ids[long_rows][:, -1] == tk.eot).all())
+    hf = tk(TOKENIZER_PROMPTS[:3], pad="eot")
+    assert bool((hf[2, 1:] == tk.eot).all()) and int(hf[2, 0]) == tk.sot
+
+
+def test_clip_tokenizer_small_merge_list():
+    from perceptor_amd.utils.tokenizer import ClipTokenizer
+    tk = ClipTokenizer(merges=[("a", "b"), ("ab", "c</w>"), ("c", "a")])
+    base = 512
+    assert tk.encode("abc") == [base + 1]                       # a b c</w> -> ab c</w> -> abc</w>
+    assert tk.encode("cab") == [base + 2, tk.ids["b</w>"]]      # (a, b) outranks (c, a) but "b</w>" is not "b": only c a merges
+    assert tk("abc", context_length=4).tolist() == [[tk.sot, base + 1, tk.eot, 0]]
+    with pytest.raises(FileNotFoundError):
+        ClipTokenizer("/nonexistent/bpe.txt.gz")

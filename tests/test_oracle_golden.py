@@ -212,3 +212,19 @@ def test_vdiff_yfcc1_wikiart(name, res, spec_fn, gain):
     sd = synth_state_dict(vdiff.state_dict_shapes(spec), 0, gain=gain)
     y = vdiff.vdiff_forward(sd, spec, g["x"], g["t"])
     _close(y[:, :, ::2, ::2], g["y_sub"], 1e-5)
+
+
+@pytest.mark.parametrize("fixture, tag, quick", [("clip_text_ruclip_tiny", "tiny", True), ("clip_text_hf_tiny-wide_gelu", "tiny-wide", False),
+                                                   ("clip_text_hf_ViT-L-14_quickgelu", "ViT-L-14", True)])
+def test_text_tower_vs_reference_and_transformers(fixture, tag, quick):
+    """oracle/clip_text.py against the reference's in-tree ruclip CLIP.encode_text and against transformers'
+    CLIPTextModelWithProjection (an independent implementation) on the same name-keyed weights (oracle/gen_golden.py: gen_clip_text)."""
+    from oracle import clip_text
+    g = golden(fixture)
+    cfg = clip_text.TEXT_CONFIGS[tag]
+    sd = synth_state_dict(clip_text.text_state_dict_shapes(cfg), 0)
+    with torch.no_grad():
+        hidden, pooled = clip_text.text_forward(sd, cfg, g["ids"], quick)
+    assert float((pooled - g["pooled"]).abs().max()) < 2e-5 * (1 + float(g["pooled"].abs().max()))
+    if "hidden" in g:
+        assert float((hidden - g["hidden"]).abs().max()) < 2e-5 * (1 + float(g["hidden"].abs().max()))
