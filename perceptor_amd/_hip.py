@@ -78,6 +78,9 @@ _PROTOS = {
     "pmi_vit_attn_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P],),
     "pmi_prep_input": ([_P, _P, _I, _P, _I, _I, _I, _I, _I, _P],),
     "pmi_finish_output": ([_P, _I, _P, _I, _I, _I, _I, _P],),
+    "pmi_nchw_to_nhwc": ([_P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P],),
+    "pmi_nhwc_to_nchw": ([_P, _I, _P, _I, _I, _I, _I, _F, _F, _P],),
+    "pmi_geglu": ([_P, _P, _L, _I, _I, _P],),
     "pmi_avgpool2": ([_P, _P, _I, _I, _I, _I, _I, _P],),
     "pmi_upsample_bilinear2": ([_P, _P, _I, _I, _I, _I, _I, _P],),
     "pmi_upsample_nearest2": ([_P, _P, _I, _I, _I, _I, _P],),

@@ -45,6 +45,56 @@ __global__ __launch_bounds__(256) void finish_output_kernel(const float* __restr
   }
 }
 
+// NCHW fp32 (C channels) -> NHWC 16-bit with Cpad channels, x = in*mul + add, zero padding channels (SD latents / VAE input)
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, u16* __restrict__ x, int N, int C, int HW, int Cpad,
+                                                           float mul, float add) {
+  const int C8 = Cpad >> 3;
+  const int64_t total = (int64_t)N * HW * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int n = (int)(pix / HW);
+    const int64_t p = pix - (int64_t)n * HW;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c8 * 8 + e;
+      f[e] = c < C ? in[((int64_t)n * C + c) * HW + p] * mul + add : 0.f;
+    }
+    store8<T>(x + pix * row_elems<T>(Cpad), c8 * 8, Cpad, f);
+  }
+}
+
+// NHWC fp32 (ld channels per pixel) -> NCHW fp32 first cout channels, out = y*mul + add
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ y, int ld, float* __restrict__ out, int N, int HW, int cout,
+                                                           float mul, float add) {
+  const int64_t total = (int64_t)N * cout * HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i % HW;
+    const int64_t nc = i / HW;
+    const int c = (int)(nc % cout), n = (int)(nc / cout);
+    out[i] = y[((int64_t)n * HW + p) * ld + c] * mul + add;
+  }
+}
+
+// GEGLU (stable_diffusion/attention.py:346-348): h[M][2F] 16-bit = (value | gate) -> out[M][F] = value * gelu(gate)
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_kernel(const u16* __restrict__ h, u16* __restrict__ out, int64_t M, int F) {
+  const int F8 = F >> 3;
+  const int64_t total = M * F8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % F8);
+    const int64_t r = i / F8;
+    float v[8], g[8];
+    unpack8<T>(*(const uint4*)(h + r * 2 * F + c8 * 8), v);
+    unpack8<T>(*(const uint4*)(h + r * 2 * F + F + c8 * 8), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= 0.5f * g[e] * (1.f + fast_erff(g[e] * 0.70710678118654752f));
+    *(uint4*)(out + r * F + c8 * 8) = pack8<T>(v);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool2_kernel(const u16* __restrict__ x, u16* __restrict__ y, int N, int H, int W, int C) {
   const int C8 = C >> 3, Ho = H / 2, Wo = W / 2;
@@ -247,6 +297,27 @@ extern "C" int pmi_prep_input(const float* img, const float* planes, int nplanes
 extern "C" int pmi_finish_output(const float* y, int ld, float* out, int N, int H, int W, int cout, pmi_stream_t s) {
   if (!y || !out || N <= 0 || cout <= 0 || cout > ld) return PMI_ERR_ARG;
   hipLaunchKernelGGL(finish_output_kernel, dim3(grid_for((int64_t)N * cout * H * W)), dim3(256), 0, ST, y, ld, out, N, H * W, cout);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_nchw_to_nhwc(const float* in, void* x, int N, int C, int H, int W, int Cpad, float mul, float add, int dtype, pmi_stream_t s) {
+  if (!in || !x || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (Cpad & 7) || Cpad < C) return PMI_ERR_ARG;
+  dim3 grid(grid_for((int64_t)N * H * W * (Cpad / 8))), block(256);
+  BY_DTYPE(nchw_to_nhwc_kernel, in, (u16*)x, N, C, H * W, Cpad, mul, add);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_nhwc_to_nchw(const float* y, int ld, float* out, int N, int H, int W, int cout, float mul, float add, pmi_stream_t s) {
+  if (!y || !out || N <= 0 || cout <= 0 || cout > ld) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((int64_t)N * cout * H * W)), dim3(256), 0, ST, y, ld, out, N, H * W, cout, mul, add);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_geglu(const void* h, void* out, int64_t M, int F, int dtype, pmi_stream_t s) {
+  if (!h || !out || M <= 0 || F <= 0 || (F & 7) || dtype == PMI_DT_F16X2) return PMI_ERR_ARG;
+  dim3 grid(grid_for(M * (F / 8))), block(256);
+  if (dtype == PMI_DT_BF16) hipLaunchKernelGGL(geglu_kernel<BF16>, grid, block, 0, ST, (const u16*)h, (u16*)out, M, F);
+  else hipLaunchKernelGGL(geglu_kernel<F16>, grid, block, 0, ST, (const u16*)h, (u16*)out, M, F);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }

@@ -399,6 +399,28 @@ def attention(qkv: torch.Tensor, heads: int, order: int, dt: int, causal: bool =
     return out
 
 
+def cross_attention(q: torch.Tensor, kv: torch.Tensor, heads: int, dt: int) -> torch.Tensor:
+    """softmax(q k^T d^-1/2) v with keys / values from another sequence (stable_diffusion/attention.py:268-298, the fused call at :285).
+    q [N, T, C], kv [N, Tc, 2C] = (k | v) x (head, d), 16-bit -> [N, T, C].  Batched MFMA GEMMs + fp32 softmax (Tc = 77 prompt tokens)."""
+    n, t, c = q.shape
+    tc = kv.shape[1]
+    assert kv.shape[0] == n and kv.shape[2] == 2 * c
+    d = c // heads
+    assert d % 8 == 0, "head dim must be a multiple of 8"
+    tcp = (tc + 7) // 8 * 8
+    dev = q.device
+    s = _empty((n * heads, t, tcp), torch.float32, dev)
+    bgemm(q, kv, s, M=t, N=tc, K=d, lda=c, ldb=2 * c, ldd=tcp, batch=n * heads, batch_inner=heads,
+          sA=(t * c, d), sB=(tc * 2 * c, d), sD=(heads * t * tcp, t * tcp), dt=dt)
+    p = _empty((n * heads, t, tcp), q.dtype, dev)
+    call("pmi_softmax_fwd", ptr(s), ptr(p), n * heads * t, tc, tcp, tcp, float(d) ** -0.5, dt)
+    vt = _transpose16(kv, c, tc, d, 2 * c, tc * 2 * c, d, heads, n * heads)
+    out = _empty((n, t, c), q.dtype, dev)
+    bgemm(p, vt, out, M=t, N=d, K=tcp, lda=tcp, ldb=tcp, ldd=c, batch=n * heads, batch_inner=heads,
+          sA=(heads * t * tcp, t * tcp), sB=(heads * d * tcp, d * tcp), sD=(t * c, d), dt=dt)
+    return out
+
+
 def _transpose16(src: torch.Tensor, off: int, rows: int, cols: int, ld: int, s_o: int, s_i: int, inner: int, batch: int) -> torch.Tensor:
     rp = (rows + 7) // 8 * 8
     out = _empty((batch, cols, rp), src.dtype, src.device)

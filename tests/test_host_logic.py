@@ -189,3 +189,19 @@ def test_clip_tokenizer_small_merge_list():
     assert tk("abc", context_length=4).tolist() == [[tk.sot, base + 1, tk.eot, 0]]
     with pytest.raises(FileNotFoundError):
         ClipTokenizer("/nonexistent/bpe.txt.gz")
+
+
+def test_sd_parameter_inventory_matches_published_figures():
+    """The SD-v1 UNet has 686 state-dict tensors and 859 520 964 parameters, the VAE decoder (+ post_quant_conv) 49 490 199 (published
+    figures of the CompVis/runwayml v1 checkpoints): pins the restated architecture's shape inventory, engine and oracle independently."""
+    from oracle import sd as osd
+    from perceptor_amd.engine import sd
+    count = lambda S: sum(int(torch.Size(s).numel()) for s in S.values())
+    for S in (osd.unet_state_dict_shapes(osd.SD_V1), sd.unet_state_dict_shapes(sd.SD_V1)):
+        assert len(S) == 686 and count(S) == 859_520_964
+    assert osd.unet_state_dict_shapes(osd.SD_V1) == sd.unet_state_dict_shapes(sd.SD_V1)
+    for S in (osd.vae_decoder_state_dict_shapes(osd.VAE_V1), sd.vae_decoder_state_dict_shapes(sd.VAE_V1)):
+        assert count(S) == 49_490_199
+    a, s = osd.schedule()
+    assert a.shape == (1000,) and abs(float(a[0]) ** 2 - (1 - 0.00085)) < 1e-6 and abs(float(a[-1]) ** 2 - 0.0046602) < 1e-5
+    assert torch.allclose(a ** 2 + s ** 2, torch.ones(1000), atol=1e-6)
