@@ -148,6 +148,38 @@ def vae_decoder_state_dict_shapes(cfg: VaeConfig) -> Dict[str, Tuple[int, ...]]:
     return S
 
 
+def vae_encoder_state_dict_shapes(cfg: VaeConfig) -> Dict[str, Tuple[int, ...]]:
+    S: Dict[str, Tuple[int, ...]] = {}
+
+    def conv(k, o, i, ks):
+        S[k + ".weight"] = (o, i, ks, ks); S[k + ".bias"] = (o,)
+
+    def norm(k, c):
+        S[k + ".weight"] = (c,); S[k + ".bias"] = (c,)
+
+    def resnet(k, i, o):
+        norm(k + ".norm1", i); conv(k + ".conv1", o, i, 3); norm(k + ".norm2", o); conv(k + ".conv2", o, o, 3)
+        if i != o:
+            conv(k + ".conv_shortcut", o, i, 1)
+
+    conv("encoder.conv_in", cfg.block_out[0], cfg.out_channels, 3)
+    ch = cfg.block_out[0]
+    for i, o in enumerate(cfg.block_out):
+        for j in range(cfg.layers_per_block):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}", ch, o)
+            ch = o
+        if i != len(cfg.block_out) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", o, o, 3)
+    resnet("encoder.mid_block.resnets.0", ch, ch); resnet("encoder.mid_block.resnets.1", ch, ch)
+    a = "encoder.mid_block.attentions.0"
+    norm(a + ".group_norm", ch)
+    for nm in ("query", "key", "value", "proj_attn"):
+        S[f"{a}.{nm}.weight"] = (ch, ch); S[f"{a}.{nm}.bias"] = (ch,)
+    norm("encoder.conv_norm_out", ch); conv("encoder.conv_out", 2 * cfg.latent_channels, ch, 3)
+    conv("quant_conv", 2 * cfg.latent_channels, 2 * cfg.latent_channels, 1)
+    return S
+
+
 def timestep_embedding(t, dim):
     half = dim // 2
     freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
@@ -228,6 +260,32 @@ def unet_forward(sd, cfg: SdConfig, sample, timesteps, context):
         if i != len(bo) - 1:
             h = _conv(F.interpolate(h, scale_factor=2.0, mode="nearest"), sd, f"up_blocks.{i}.upsamplers.0.conv")
     return _conv(F.silu(_gn(h, sd, "conv_norm_out", g, 1e-5)), sd, "conv_out")
+
+
+def _vae_attention(sd, a, h, g):
+    n, c, hh, ww = h.shape
+    z = _gn(h, sd, a + ".group_norm", g, 1e-6).reshape(n, c, hh * ww).transpose(1, 2)
+    q, k, v = (F.linear(z, sd[f"{a}.{nm}.weight"], sd[f"{a}.{nm}.bias"]) for nm in ("query", "key", "value"))
+    p = torch.softmax((q * c ** -0.25) @ (k * c ** -0.25).transpose(-1, -2), dim=-1)
+    z = F.linear(p @ v, sd[a + ".proj_attn.weight"], sd[a + ".proj_attn.bias"])
+    return z.transpose(1, 2).reshape(n, c, hh, ww) + h
+
+
+def vae_encode_moments(sd, cfg: VaeConfig, x):
+    """AutoencoderKL.encode(x).latent_dist parameters: x in [-1, 1] [N, 3, H, W] -> (mean, logvar) [N, 4, H/8, W/8] each
+    (mode() = mean; stable_diffusion.py:185-190 multiplies by 0.18215).  Down-sampling pads right/bottom only, then a stride-2 conv."""
+    g = cfg.groups
+    h = _conv(x, sd, "encoder.conv_in")
+    for i in range(len(cfg.block_out)):
+        for j in range(cfg.layers_per_block):
+            h = _resnet(sd, f"encoder.down_blocks.{i}.resnets.{j}", h, None, g, 1e-6)
+        if i != len(cfg.block_out) - 1:
+            h = _conv(F.pad(h, (0, 1, 0, 1)), sd, f"encoder.down_blocks.{i}.downsamplers.0.conv", stride=2, pad=0)
+    h = _resnet(sd, "encoder.mid_block.resnets.0", h, None, g, 1e-6)
+    h = _vae_attention(sd, "encoder.mid_block.attentions.0", h, g)
+    h = _resnet(sd, "encoder.mid_block.resnets.1", h, None, g, 1e-6)
+    h = _conv(F.silu(_gn(h, sd, "encoder.conv_norm_out", g, 1e-6)), sd, "encoder.conv_out")
+    return _conv(h, sd, "quant_conv", pad=0).chunk(2, dim=1)
 
 
 def vae_decode(sd, cfg: VaeConfig, latents):

@@ -158,6 +158,26 @@ def vae_decoder_state_dict_shapes(cfg: VaeConfig) -> Dict[str, Tuple[int, ...]]:
     return sh.S
 
 
+def vae_encoder_state_dict_shapes(cfg: VaeConfig) -> Dict[str, Tuple[int, ...]]:
+    sh = _Shapes()
+    sh.conv("encoder.conv_in", cfg.block_out[0], cfg.out_channels, 3)
+    ch = cfg.block_out[0]
+    for i, o in enumerate(cfg.block_out):
+        for j in range(cfg.layers_per_block):
+            sh.resnet(f"encoder.down_blocks.{i}.resnets.{j}", ch, o)
+            ch = o
+        if i != len(cfg.block_out) - 1:
+            sh.conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", o, o, 3)
+    sh.resnet("encoder.mid_block.resnets.0", ch, ch); sh.resnet("encoder.mid_block.resnets.1", ch, ch)
+    a = "encoder.mid_block.attentions.0"
+    sh.norm(a + ".group_norm", ch)
+    for nm in ("query", "key", "value", "proj_attn"):
+        sh.lin(f"{a}.{nm}", ch, ch)
+    sh.norm("encoder.conv_norm_out", ch); sh.conv("encoder.conv_out", 2 * cfg.latent_channels, ch, 3)
+    sh.conv("quant_conv", 2 * cfg.latent_channels, 2 * cfg.latent_channels, 1)
+    return sh.S
+
+
 class _Blocks:
     """What the UNet and the VAE decoder share: packed weights by key and the ResnetBlock2D launch sequence."""
 
@@ -193,6 +213,28 @@ class _Blocks:
         skip = ops.igemm(x, w[k + ".skip"], a1=x1) if (k + ".skip") in w else x
         assert (k + ".skip") in w or x1 is None
         return ops.igemm(h, w[k + ".conv2"], residual=skip, prologue=(ca, cb, ACT_SILU), want_stats=True)
+
+
+    def _pack_vae_attention(self, a):
+        sd = self.sd
+        self.w[a + ".gn"] = (self._f32(a + ".group_norm.weight"), self._f32(a + ".group_norm.bias"))
+        self.w[a + ".qkv"] = PackedLinear(torch.cat([sd[f"{a}.{nm}.weight"].float() for nm in ("query", "key", "value")], 0),
+                                          torch.cat([sd[f"{a}.{nm}.bias"].float() for nm in ("query", "key", "value")], 0), self.dt, self.device)
+        self.w[a + ".proj"] = self._lin(a + ".proj_attn")
+
+    def _vae_attention(self, a, h, groups):
+        """AttentionBlock (stable_diffusion/attention.py:71-117): GroupNorm -> q|k|v -> one head over all pixels -> proj + residual."""
+        dt, w = self.dt, self.w
+        n, h2, w2, cc = h.shape
+        m = n * h2 * w2
+        hn = ops.group_norm(h, *w[a + ".gn"], groups, dt, eps=1e-6)
+        qkv = ops.igemm(hn.view(m, cc), w[a + ".qkv"])
+        at = ops.attention(qkv.view(n, h2 * w2, 3 * cc), 1, 1, dt)
+        o = ops.igemm(at.view(m, cc), w[a + ".proj"], residual=h.view(m, cc), want_stats=True, hw=h2 * w2)
+        h4 = o.view(n, h2, w2, cc)
+        if hasattr(o, "_pmi_stats"):
+            h4._pmi_stats = o._pmi_stats
+        return h4
 
 
 class SdUnetEngine(_Blocks):
@@ -343,11 +385,7 @@ class VaeDecoderEngine(_Blocks):
         self.pq = PackedLinear(wq, bq, self.dt, self.device, cin_pad=lp)
         self.conv_in = self._lin("decoder.conv_in", cin_pad=lp)
         self._pack_resnet("decoder.mid_block.resnets.0"); self._pack_resnet("decoder.mid_block.resnets.1")
-        a = "decoder.mid_block.attentions.0"
-        self.w[a + ".gn"] = (self._f32(a + ".group_norm.weight"), self._f32(a + ".group_norm.bias"))
-        self.w[a + ".qkv"] = PackedLinear(torch.cat([sd[f"{a}.{nm}.weight"].float() for nm in ("query", "key", "value")], 0),
-                                          torch.cat([sd[f"{a}.{nm}.bias"].float() for nm in ("query", "key", "value")], 0), self.dt, self.device)
-        self.w[a + ".proj"] = self._lin(a + ".proj_attn")
+        self._pack_vae_attention("decoder.mid_block.attentions.0")
         self.plan = []
         for i, o in enumerate(reversed(cfg.block_out)):
             for j in range(cfg.layers_per_block + 1):
@@ -379,16 +417,7 @@ class VaeDecoderEngine(_Blocks):
         h = ops.igemm(z, self.conv_in, want_stats=True)
         g, eps = cfg.groups, 1e-6
         h = self._resnet("decoder.mid_block.resnets.0", h, None, None, g, eps)
-        a = "decoder.mid_block.attentions.0"
-        _, h2, w2, cc = h.shape
-        m = n * h2 * w2
-        hn = ops.group_norm(h, *w[a + ".gn"], g, dt, eps=eps)
-        qkv = ops.igemm(hn.view(m, cc), w[a + ".qkv"])
-        at = ops.attention(qkv.view(n, h2 * w2, 3 * cc), 1, 1, dt)
-        o = ops.igemm(at.view(m, cc), w[a + ".proj"], residual=h.view(m, cc), want_stats=True, hw=h2 * w2)
-        h4 = o.view(n, h2, w2, cc)
-        if hasattr(o, "_pmi_stats"):
-            h4._pmi_stats = o._pmi_stats
+        h4 = self._vae_attention("decoder.mid_block.attentions.0", h, g)
         h = self._resnet("decoder.mid_block.resnets.1", h4, None, None, g, eps)
         for kind, k in self.plan:
             h = self._resnet(k, h, None, None, g, eps) if kind == "res" else ops.igemm(h, w[k], up=True, want_stats=True)
@@ -399,3 +428,66 @@ class VaeDecoderEngine(_Blocks):
         mul, add = (0.5, 0.5) if to_images else (1.0, 0.0)          # diffusion_space.decode: (x + 1) / 2
         call("pmi_nhwc_to_nchw", ptr(y), y.shape[-1], ptr(out), n, ho, wo, cfg.out_channels, mul, add)
         return out
+
+
+class VaeEncoderEngine(_Blocks):
+    """AutoencoderKL.encode (stable_diffusion.py:176-192): images -> 2*img-1 -> encoder -> quant_conv -> (mean, logvar)."""
+
+    def __init__(self, cfg: VaeConfig, state_dict: Dict[str, torch.Tensor], device, dtype="bf16"):
+        self._init_common(state_dict, device, dtype)
+        self.cfg = cfg
+        self.conv_in = self._lin("encoder.conv_in", cin_pad=8)
+        self.plan = []
+        for i, o in enumerate(cfg.block_out):
+            for j in range(cfg.layers_per_block):
+                k = f"encoder.down_blocks.{i}.resnets.{j}"
+                self._pack_resnet(k)
+                self.plan.append(("res", k))
+            if i != len(cfg.block_out) - 1:
+                k = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+                self.w[k] = self._lin(k)
+                self.plan.append(("down", k))
+        self._pack_resnet("encoder.mid_block.resnets.0"); self._pack_resnet("encoder.mid_block.resnets.1")
+        self._pack_vae_attention("encoder.mid_block.attentions.0")
+        self.gn_out = (self._f32("encoder.conv_norm_out.weight"), self._f32("encoder.conv_norm_out.bias"))
+        self.conv_out = self._lin("encoder.conv_out")
+        self.quant = (self._f32("quant_conv.weight").flatten(1), self._f32("quant_conv.bias"))
+        self.sd = None
+
+    def _down(self, h, lin):
+        """Downsample2D(padding=0): pad right/bottom by one, 3x3 stride-2 conv without padding.  Run as the symmetric pad-1 stride-2
+        convolution on a copy with a one-pixel zero frame: its output (oy+1, ox+1) reads exactly x[2oy..2oy+2, 2ox..2ox+2]."""
+        n, hh, ww, c = h.shape
+        xp = torch.zeros((n, hh + 2, ww + 2, c), dtype=h.dtype, device=h.device)
+        xp[:, 1:hh + 1, 1:ww + 1] = h
+        return ops.igemm(xp, lin, stride=2)[:, 1:, 1:].contiguous()
+
+    @torch.no_grad()
+    def forward(self, images: torch.Tensor):
+        """images NCHW fp32 in [0, 1] -> (mean, logvar) NCHW fp32 [N, latent, H/8, W/8] of the latent distribution."""
+        cfg, dt, dev, w = self.cfg, self.dt, self.device, self.w
+        if not images.is_cuda:
+            raise RuntimeError("VaeEncoderEngine runs on a HIP device only (no CPU fallback)")
+        images = images.float().contiguous()
+        n, c, hh, ww = images.shape
+        down = 1 << (len(cfg.block_out) - 1)
+        if c != cfg.out_channels or hh % down or ww % down:
+            raise ValueError(f"images must be [N, {cfg.out_channels}, H, W] with H, W divisible by {down}")
+        x = torch.empty((n, hh, ww, 8), dtype=_hip.TORCH_DTYPE[dt], device=dev)
+        call("pmi_nchw_to_nhwc", ptr(images), ptr(x), n, c, hh, ww, 8, 2.0, -1.0, dt)      # diffusion_space.encode: 2*img - 1
+        h = ops.igemm(x, self.conv_in, want_stats=True)
+        g, eps = cfg.groups, 1e-6
+        for kind, k in self.plan:
+            h = self._resnet(k, h, None, None, g, eps) if kind == "res" else self._down(h, w[k])
+        h = self._resnet("encoder.mid_block.resnets.0", h, None, None, g, eps)
+        h = self._vae_attention("encoder.mid_block.attentions.0", h, g)
+        h = self._resnet("encoder.mid_block.resnets.1", h, None, None, g, eps)
+        ca, cb = ops.group_norm_coeffs(h, *self.gn_out, g, dt, eps=eps)
+        y = ops.igemm(h, self.conv_out, out_f32=True, prologue=(ca, cb, ACT_SILU))        # [n, h/8, w/8, 8] fp32
+        _, ho, wo, c2 = y.shape
+        m = n * ho * wo
+        mom = ops.linear_f32(y.view(m, c2), self.quant[0], self.quant[1])                  # quant_conv (1x1, 8 -> 8) in exact fp32
+        out = torch.empty((n, c2, ho, wo), dtype=torch.float32, device=dev)
+        call("pmi_nhwc_to_nchw", ptr(mom), c2, ptr(out), n, ho, wo, c2, 1.0, 0.0)
+        lc = cfg.latent_channels
+        return out[:, :lc].contiguous(), out[:, lc:2 * lc].contiguous()

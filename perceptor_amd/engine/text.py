@@ -45,6 +45,27 @@ def text_state_dict_shapes(cfg) -> Dict[str, Tuple[int, ...]]:
     return S
 
 
+def from_hf_text_state_dict(hf: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """transformers' CLIPTextModel(WithProjection) state dict (``text_model.encoder.layers.{i}.self_attn.q_proj...``, the form the
+    reference loads at stable_diffusion.py:299-301 and transformers_openai_clip.py:90) -> the OpenAI-CLIP names this engine packs."""
+    g = lambda k: hf[k].detach().float()
+    out = {"token_embedding.weight": g("text_model.embeddings.token_embedding.weight"),
+           "positional_embedding": g("text_model.embeddings.position_embedding.weight"),
+           "ln_final.weight": g("text_model.final_layer_norm.weight"), "ln_final.bias": g("text_model.final_layer_norm.bias")}
+    if "text_projection.weight" in hf:
+        out["text_projection"] = g("text_projection.weight").t().contiguous()
+    i = 0
+    while f"text_model.encoder.layers.{i}.layer_norm1.weight" in hf:
+        a, b = f"text_model.encoder.layers.{i}.", f"transformer.resblocks.{i}."
+        out[b + "attn.in_proj_weight"] = torch.cat([g(a + f"self_attn.{n}_proj.weight") for n in "qkv"], dim=0)
+        out[b + "attn.in_proj_bias"] = torch.cat([g(a + f"self_attn.{n}_proj.bias") for n in "qkv"], dim=0)
+        for src, dst in (("self_attn.out_proj", "attn.out_proj"), ("layer_norm1", "ln_1"), ("layer_norm2", "ln_2"),
+                         ("mlp.fc1", "mlp.c_fc"), ("mlp.fc2", "mlp.c_proj")):
+            out[b + dst + ".weight"], out[b + dst + ".bias"] = g(a + src + ".weight"), g(a + src + ".bias")
+        i += 1
+    return out
+
+
 class TextEngine:
     def __init__(self, cfg, state_dict, device, dtype="bf16", quick_gelu=True):
         self.cfg, self.device = cfg, torch.device(device)

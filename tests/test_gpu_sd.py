@@ -73,3 +73,107 @@ def test_vae_decoder_vs_oracle(dtype):
         d = (got - want)
         emax, el2 = float(d.abs().max() / (want - 0.5).abs().max()), float(d.norm() / (want - 0.5).norm())
         assert emax < TOL[dtype][0] and el2 < TOL[dtype][1], (ocfg.block_out, emax, el2)
+
+
+TINY_TEXT = (16, 520, 32, 2, 1, 32)        # context, vocab, width (= the tiny UNet's context_dim), layers, heads, out_dim
+
+
+def _tiny_model(fp16=True):
+    from perceptor_amd import models
+    from perceptor_amd.engine import sd
+    cfg = sd.SdConfig(block_out=(32, 64, 64), cross_attn=(True, True, False), heads=2, context_dim=32)
+    vae = sd.VaeConfig(block_out=(32, 64), layers_per_block=1)
+    return models.StableDiffusion(fp16=fp16, config=cfg, vae_config=vae, text_config=TINY_TEXT).to("cuda")
+
+
+def test_class_surface_step_cfg_decode_encode_vs_oracle():
+    from oracle import clip_text, sd as osd
+    from perceptor_amd.utils.synth import seeded_noise, synth_state_dict
+    m = _tiny_model()
+    sdk = m.state_dict()
+    assert sum(k.startswith("unet.") for k in sdk) == 494 and "schedule_alphas" in sdk and any(k.startswith("vae.encoder.") for k in sdk)
+    a_ref, s_ref = osd.schedule()
+    assert torch.equal(m.schedule_alphas.cpu(), a_ref) and torch.equal(m.schedule_sigmas.cpu(), s_ref)
+    ids = torch.tensor([[518, 5, 9, 300, 519] + [519] * 11, [518, 519] + [519] * 14])
+    pos, neu = m.conditioning(token_ids=ids[:1]), m.conditioning(token_ids=ids[1:])
+    tsd = synth_state_dict({k: v for k, v in clip_text.text_state_dict_shapes(TINY_TEXT).items()}, 0)
+    want_h, _ = clip_text.text_forward(tsd, TINY_TEXT, ids, True)
+    assert float((pos.encodings.cpu() - want_h[:1]).abs().max()) < 5e-3 * float(want_h.abs().max())
+    x = seeded_noise((2, 4, 16, 16), 81).cuda()
+    un, po = m.predictions_pair(x, 600, neu, pos)
+    usd = synth_state_dict(osd.unet_state_dict_shapes(osd.SD_TINY), 0)
+    t = torch.tensor([600, 600])
+    with torch.no_grad():
+        e_un = osd.unet_forward(usd, osd.SD_TINY, x.cpu(), t, want_h[1:].expand(2, -1, -1))
+        e_po = osd.unet_forward(usd, osd.SD_TINY, x.cpu(), t, want_h[:1].expand(2, -1, -1))
+    for got, want in ((un.predicted_noise, e_un), (po.predicted_noise, e_po)):
+        emax, el2 = _err(got.cpu(), want)
+        assert emax < TOL["f16"][0] and el2 < TOL["f16"][1], (emax, el2)
+    sep = m.predictions(x, 600, pos)                     # the batched pair equals a separate call (rounding-level: tile choices depend on M)
+    assert _err(sep.predicted_noise.cpu(), po.predicted_noise.cpu())[0] < 2e-3
+    # algebra on the SAME predicted noise: cfg, step, denoised, forced, resample bounds (stable_diffusion/predictions.py)
+    a, s, a2, s2 = a_ref[600], s_ref[600], a_ref[560], s_ref[560]
+    strong = un.classifier_free_guidance(po, guidance_scale=7.0)
+    e_cfg = osd.classifier_free_guidance(un.predicted_noise.cpu(), po.predicted_noise.cpu(), 7.0)
+    assert float((strong.predicted_noise.cpu() - e_cfg).abs().max()) < 1e-5 * (1 + float(e_cfg.abs().max()))
+    nxt = strong.step(560)
+    want = osd.ddim_step(x.cpu(), e_cfg, a, s, a2, s2)
+    assert float((nxt.cpu() - want).abs().max()) < 2e-5 * (1 + float(want.abs().max()))
+    den = osd.denoised_latents(x.cpu(), e_cfg, a, s)
+    assert float((strong.denoised_latents.cpu() - den).abs().max()) < 2e-5 * (1 + float(den.abs().max()))
+    forced = strong.forced_denoised_latents(strong.denoised_latents)
+    assert float((forced.predicted_noise - strong.predicted_noise).abs().max()) < 1e-4 * (1 + float(e_cfg.abs().max()))
+    assert strong.reverse_step(700).shape == x.shape
+    with pytest.raises(ValueError):
+        strong.reverse_step(100)
+    with pytest.raises(ValueError):
+        strong.resample_noise(900)
+    thr = strong.latent_dynamic_threshold(0.5)
+    assert float(thr.predicted_noise.abs().max()) <= max(2.5, float(strong.predicted_noise.abs().flatten(1).quantile(0.5, dim=1).max())) + 1e-5
+    # VAE: decode / encode against the oracle on the name-keyed weights
+    vsd = synth_state_dict({**osd.vae_encoder_state_dict_shapes(osd.VAE_TINY), **osd.vae_decoder_state_dict_shapes(osd.VAE_TINY)}, 0)
+    z = seeded_noise((1, 4, 16, 16), 82)
+    with torch.no_grad():
+        img = (osd.vae_decode(vsd, osd.VAE_TINY, z / 0.18215) + 1) / 2
+    got = m.decode(z.cuda()).cpu()
+    assert float((got - img).abs().max()) < 4e-2 * float((img - 0.5).abs().max())
+    pic = (seeded_noise((1, 3, 32, 32), 83) * 0.25 + 0.5)
+    with torch.no_grad():
+        mean, _ = osd.vae_encode_moments(vsd, osd.VAE_TINY, pic * 2 - 1)
+    lat = m.latents(pic.cuda()).cpu()
+    assert float((lat - 0.18215 * mean).abs().max()) < 4e-2 * float((0.18215 * mean).abs().max())
+    assert m.encode(pic.cuda(), method="sample").shape == lat.shape
+    with pytest.raises(Exception):
+        m.encode(torch.zeros(1, 3, 40, 32).cuda())
+    with pytest.raises(ValueError):
+        m.encode(pic.cuda(), method="nope")
+    assert strong.dynamic_threshold(0.95).predicted_noise.shape == x.shape        # decode -> clamp -> encode round trip runs
+
+
+def test_sample_loop_schedule_and_errors():
+    from perceptor_amd import models
+    from perceptor_amd.utils.tokenizer import ClipTokenizer
+    m = _tiny_model()
+    idx = m.schedule_indices(n_steps=50)
+    assert idx.shape[1] == 2 and int(idx[0, 0]) == 999 and bool((idx[:, 0] > idx[:, 1]).all()) and bool((idx[1:, 0] == idx[:-1, 1]).all())
+    with pytest.raises(ValueError):
+        m.schedule_indices(from_index=10, to_index=20)
+    with pytest.raises(ValueError):
+        m.schedule_indices(n_steps=1000)                    # collapses below 0.9 * n_steps: ValueError here (AssertionError in GuidedDiffusion)
+    with pytest.raises(FileNotFoundError):
+        m.conditioning(["a cab"])                           # the merge list is data the caller provides
+    m._tokenizer = ClipTokenizer(merges=[("a", "b"), ("ab", "c</w>"), ("c", "a")])
+    assert m.tokenize(["abc"]).tolist()[0][:4] == [m._tokenizer.sot, 513, m._tokenizer.eot, m._tokenizer.eot]
+    outs = list(m.sample("abc cab", n_steps=4, to_index=600, guidance_scale=3.0))
+    assert len(outs) == len(m.schedule_indices(n_steps=4, to_index=600)) + 1
+    assert outs[-1].predicted_noise.shape == (1, 4, 64, 64) and bool(torch.isfinite(outs[-1].predicted_noise).all())
+    img = outs[-1].denoised_images
+    assert img.shape == (1, 3, 128, 128) and bool(torch.isfinite(img).all())     # the tiny VAE up-samples x2 (two levels)
+    with pytest.raises(ValueError):
+        m.random_diffused_latents((1, 3, 500, 512))
+    with pytest.raises(ValueError):
+        next(m.sample("abc", from_index=500))
+    with pytest.raises(NotImplementedError):
+        models.StableDiffusion("runwayml/stable-diffusion-inpainting")
+    with pytest.raises(RuntimeError):
+        models.StableDiffusion(weights="pretrained")
