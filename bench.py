@@ -42,6 +42,7 @@ CONFIGS = {
     "c2": ("standard", 256, 4, None),
     "c3": ("yfcc_2", 512, 8, "ViT-B-32"),
     "c5-noclip": ("standard", 512, 8, None),
+    "c4": ("stable-diffusion-v1", 512, 4, None),      # configs[3]: SD-v1 latent UNet 512x512 with CFG, batch 32 over 8 GPUs = 4 per GPU
     "smoke": ("pixelart", 64, 2, None),
 }
 
@@ -55,6 +56,7 @@ def parse():
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "precise"],
                    help="UNet arithmetic: bf16 / f16 single-pass MFMA, or precise (hi + lo f16 pairs, eps max-abs error < 1e-3 vs the fp32 reference)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--sd-bf16", action="store_true", help="config c4: bf16 operands instead of the f16 the reference runs SD in")
     p.add_argument("--no-kernel-events", action="store_true")
     p.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (helps launch-bound small configs such as c1)")
     p.add_argument("--dump-kernels", default=None, help="write per-launch (ms, GFLOP, MB) of the timed conv3x3 launches of the last step to this file")
@@ -171,6 +173,104 @@ def cpu_baseline(model_name, res, nb, clip_arch, clip_loss, hip_model, dev, seed
     return sec_step, sample, cores, parity
 
 
+def main_sd(a, rank, world, dev, dist):
+    """config c4 (BASELINE configs[3]): one step = the unconditioned + conditioned SD-v1 UNet evaluation of a batch of
+    4 latents (one batched launch sequence, batch 8), classifier-free guidance and the DDIM update.  Prompt encodings are computed
+    once before the timed region, as in the reference's sample() (stable_diffusion.py:415-426)."""
+    from perceptor_amd import models
+    from perceptor_amd.engine import sd as sd_engine
+    from perceptor_amd.utils.synth import seeded_noise
+    _, res, nb, _ = CONFIGS["c4"]
+    dtype = "f16" if a.dtype == "bf16" and not a.sd_bf16 else a.dtype        # the reference runs SD in fp16 (fp16=True default)
+    model = models.StableDiffusion(fp16=(dtype == "f16")).to(dev)
+    ids = torch.full((2, 77), 49407, dtype=torch.int64)
+    ids[:, 0] = 49406
+    ids[1, 1:9] = torch.tensor([1125, 539, 320, 2368, 525, 320, 4558, 267])      # a fixed 8-token prompt; row 0 is the empty prompt
+    neutral, positive = model.conditioning(token_ids=ids[:1]), model.conditioning(token_ids=ids[1:])
+    lat = seeded_noise((nb * world, 4, res // 8, res // 8), 1234)[rank * nb:(rank + 1) * nb].to(dev)
+    sched = model.schedule_indices(n_steps=max(a.steps + a.warmup + 1, 50))
+
+    def one_step(lat, i):
+        fi, ti = sched[i % len(sched)]
+        un, pos = model.predictions_pair(lat, fi, neutral, positive)
+        return un.classifier_free_guidance(pos, guidance_scale=7.0).step(ti)
+
+    if a.graph:
+        from perceptor_amd.engine.graph import GraphedStep
+
+        def step_fn(x, fi, ti):
+            un, pos = model.predictions_pair(x, fi, neutral, positive)
+            return un.classifier_free_guidance(pos, guidance_scale=7.0).step(ti)
+        gstep = GraphedStep(step_fn, lat, sched[0][0], sched[0][1])
+
+        def one_step(lat, i):   # noqa: F811
+            fi, ti = sched[i % len(sched)]
+            return gstep(lat, fi, ti).clone()
+    for i in range(a.warmup):
+        lat = one_step(lat, i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ev[i][0].record()
+        lat = one_step(lat, a.warmup + i)
+        ev[i][1].record()
+    if dist is not None:
+        gathered = [torch.empty_like(lat) for _ in range(world)]
+        dist.all_gather(gathered, lat)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank != 0:
+        return
+    step_ms_dev = sum(s.elapsed_time(e) for s, e in ev) / a.steps
+    gflop_eval = sd_engine.unet_gflop(sd_engine.SD_V1, res // 8, res // 8, 77)
+    tflop_step = 2 * nb * gflop_eval / 1e3
+    achieved = tflop_step / (step_ms_dev / 1e3)
+    peak = PEAK_TFLOPS["f16" if dtype == "f16" else "bf16"]
+    out = {
+        "metric": "denoising steps/sec (c4)", "value": round(a.steps / elapsed * world, 4),
+        "unit": f"steps/s (batch-{nb} CFG steps summed over GPUs)", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": dtype, "data": "synthetic",
+        "config": {"workload": f"StableDiffusion v1 latent UNet {res}x{res} (64x64 latents), batch {nb}/GPU, classifier-free guidance "
+                               "(unconditioned + conditioned evaluation = UNet batch 8) + DDIM eta=0, 77-token CLIP ViT-L/14 text context, synthetic weights",
+                   "name": "c4", "global_batch": nb * world, "parallelism": f"replica-sharded chains x{world}"},
+        "outputs_finite": bool(torch.isfinite(lat).all().item()), "rccl_ranks": world if dist is not None else 0,
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                     "traffic": None, "kernel": "whole step (no per-kernel events on this config)",
+                     "algorithmic_gflop_per_unet_eval_per_sample": round(gflop_eval, 1)},
+    }
+    if not a.no_cpu_baseline and world == 1:
+        from oracle import sd as osd
+        sres = 16
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        usd = {k: v.detach().float().cpu() for k, v in model.unet.state_dict().items()}
+        x = seeded_noise((1, 4, sres, sres), 5)
+        ctx = positive.encodings.float().cpu()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            want = osd.unet_forward(usd, osd.SD_V1, x, torch.tensor([600]), ctx)
+        t_eval = time.perf_counter() - t0
+        got = model.predicted_noise(x.to(dev), 600, positive).cpu()
+        scale = (res // 8 / sres) ** 2 * nb * 2
+        out["cpu_baseline"] = {"value": round(1.0 / (t_eval * scale), 6), "unit": f"steps/s (batch-{nb} CFG steps)", "cores": torch.get_num_threads(),
+                               "kind": "port", "sample": f"one oracle UNet evaluation at batch 1, {sres}x{sres} latents = {t_eval:.2f}s, scaled x{scale:.0f} "
+                                                         "(pixels x batch x 2 evaluations per CFG step)"}
+        out["parity"] = {"eps_max_abs_err": float((got - want).abs().max()), "eps_max_abs": float(want.abs().max()),
+                         "sample": f"batch 1, {sres}x{sres} latents, index 600, vs the CPU fp32 oracle (parity unpinned against diffusers itself)"}
+    print(json.dumps(out), flush=True)
+
+
 def conv_kernel_name(desc):
     """Kernel a timed 3x3-convolution launch ran in, from its tile config (csrc/conv3x3.hip: pmi_conv3x3_halo_config)."""
     cfg = int(desc.split(" cfg")[1].split()[0])
@@ -195,6 +295,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if a.config == "c4":
+        main_sd(a, rank, world, dev, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     from perceptor_amd import models
     from perceptor_amd.engine import ops

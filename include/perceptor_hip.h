@@ -139,6 +139,13 @@ int pmi_gn_apply(const void* x, const void* x1, int C0, const float* coef_a, con
  * qkv_split re-tiles the qkv 1x1-conv output [N][T][3C] into Q,K [N*heads][Tp][64]
  * and V^T [N*heads][64][Tp] (Tp = T rounded up to 32, zero filled).
  * order: 0 = heads then q,k,v (legacy), 1 = q,k,v then heads (new order and v-diffusion). */
+/* Flash-style attention for head dims 8..160 (multiples of 8) with a separate key / value sequence: the StableDiffusion transformer
+ * blocks' self- and cross-attention (stable_diffusion/attention.py:268-298, replaces the xformers call at :285).
+ * q [N][T][ldq], k and v [N][Tk][ldkv] 16-bit with head h at channel offset h*d of each pointer; out [N][T][heads*d];
+ * ws: caller-owned scratch of pmi_attn_flash_workspace(...) KiB (operands re-tiled into MFMA fragment order; < 0: unsupported). */
+int pmi_attn_flash_workspace(int N, int T, int Tk, int heads, int d);
+int pmi_attn_flash(const void* q, int ldq, const void* k, const void* v, int ldkv, void* out, void* ws, int N, int T, int Tk, int heads,
+                   int d, float scale, int dtype, pmi_stream_t s);
 int pmi_qkv_split(const void* qkv, void* q, void* k, void* vt, int N, int T, int heads, int order, int dtype, pmi_stream_t s);
 int pmi_attn_d64(const void* q, const void* k, const void* vt, void* out, int N, int T, int heads, float scale,
                  int dtype, pmi_stream_t s);

@@ -72,6 +72,8 @@ _PROTOS = {
     "pmi_gn_stats": ([_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],),
     "pmi_gn_finalize": ([_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _F, _P],),
     "pmi_gn_apply": ([_P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],),
+    "pmi_attn_flash_workspace": ([_I, _I, _I, _I, _I],),
+    "pmi_attn_flash": ([_P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],),
     "pmi_qkv_split": ([_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],),
     "pmi_attn_d64": ([_P, _P, _P, _P, _I, _I, _I, _F, _I, _P],),
     "pmi_vit_attn_fwd": ([_P, _P, _P, _P, _I, _I, _I, _F, _I, _P],),

@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libperceptor_hip.so")
-SOURCES = ["igemm.hip", "conv3x3.hip", "conv_wd.hip", "gemm_wd.hip", "norm.hip", "attn.hip", "elementwise.hip", "clip.hip", "f32gemm.hip", "sampling.hip", "backward.hip"]
+SOURCES = ["igemm.hip", "conv3x3.hip", "conv_wd.hip", "gemm_wd.hip", "norm.hip", "attn.hip", "attn_flash.hip", "elementwise.hip", "clip.hip", "f32gemm.hip", "sampling.hip", "backward.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC"]
 
 

@@ -580,6 +580,8 @@ extern "C" int pmi_igemm_stats_rows(const pmi_igemm_args* a) {
   return 0;
 }
 
+void pmi_attn_flash_qt(int v);     // attn_flash.hip
+
 extern "C" int pmi_set_option(int key, int value) {
   if (key == 0) { const int old = g_allow_halo; g_allow_halo = value; return old; }
   if (key == 1) { pmi_conv3x3_force_config(value); return 0; }
@@ -587,6 +589,7 @@ extern "C" int pmi_set_option(int key, int value) {
   if (key == 6) { pmi_conv3x3_allow_wd(value); return 0; }
   if (key == 7) { pmi_conv3x3_wd_mf16(value); return 0; }
   if (key == 8) { pmi_conv3x3_wd128(value); return 0; }
+  if (key == 9) { pmi_attn_flash_qt(value); return 0; }
   return PMI_ERR_ARG;
 }
 

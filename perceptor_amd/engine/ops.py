@@ -19,6 +19,7 @@ HALO_ENABLED = True
 SPLITK_ENABLED = True
 WD_ENABLED = True       # weights-direct conv3x3 kernel (csrc/conv_wd.hip) where the shape is eligible
 GEMM_WD_ENABLED = True  # weights-direct GEMM (csrc/gemm_wd.hip) for plain GEMMs
+FLASH_ENABLED = True    # general flash attention (csrc/attn_flash.hip) instead of batched GEMMs + softmax where the head dim is not 64
 
 
 def set_halo(enabled: bool) -> None:
@@ -382,6 +383,8 @@ def attention(qkv: torch.Tensor, heads: int, order: int, dt: int, causal: bool =
         call("pmi_attn_d64", ptr(q), ptr(k), ptr(vt), ptr(out), n, t, heads, scale, dt)
         return out
     assert d % 8 == 0, "head dim must be a multiple of 8"
+    if FLASH_ENABLED and order == 1 and not causal and d <= 160:
+        return flash_attention(qkv, qkv[..., c:], qkv[..., 2 * c:], heads, d, dt)
     tp = (t + 7) // 8 * 8
     if order == 0:
         qo, ko, vo, hs = 0, d, 2 * d, 3 * d
@@ -399,6 +402,22 @@ def attention(qkv: torch.Tensor, heads: int, order: int, dt: int, causal: bool =
     return out
 
 
+def flash_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, d: int, dt: int) -> torch.Tensor:
+    """softmax(q k^T d^-1/2) v through pmi_attn_flash.  q [N, T, >= heads*d] and k, v [N, Tk, >= heads*d] are (views of) 16-bit tensors
+    whose last-dim stride is 1 and whose head h sits at channels [h*d, (h+1)*d) of the view; -> [N, T, heads*d]."""
+    n, t = q.shape[:2]
+    tk = k.shape[1]
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1 and k.stride(1) == v.stride(1)
+    assert q.stride(0) == t * q.stride(1) and k.stride(0) == tk * k.stride(1)
+    kib = _hip.lib().pmi_attn_flash_workspace(n, t, tk, heads, d)
+    if kib < 0:
+        raise ValueError(f"flash attention: unsupported head dim {d}")
+    ws = _empty((kib * 512,), q.dtype, q.device)
+    out = _empty((n, t, heads * d), q.dtype, q.device)
+    call("pmi_attn_flash", ptr(q), q.stride(1), ptr(k), ptr(v), k.stride(1), ptr(out), ptr(ws), n, t, tk, heads, d, float(d) ** -0.5, dt)
+    return out
+
+
 def cross_attention(q: torch.Tensor, kv: torch.Tensor, heads: int, dt: int) -> torch.Tensor:
     """softmax(q k^T d^-1/2) v with keys / values from another sequence (stable_diffusion/attention.py:268-298, the fused call at :285).
     q [N, T, C], kv [N, Tc, 2C] = (k | v) x (head, d), 16-bit -> [N, T, C].  Batched MFMA GEMMs + fp32 softmax (Tc = 77 prompt tokens)."""
@@ -407,6 +426,8 @@ def cross_attention(q: torch.Tensor, kv: torch.Tensor, heads: int, dt: int) -> t
     assert kv.shape[0] == n and kv.shape[2] == 2 * c
     d = c // heads
     assert d % 8 == 0, "head dim must be a multiple of 8"
+    if FLASH_ENABLED and d <= 160:
+        return flash_attention(q, kv, kv[..., c:], heads, d, dt)
     tcp = (tc + 7) // 8 * 8
     dev = q.device
     s = _empty((n * heads, t, tcp), torch.float32, dev)

@@ -113,6 +113,32 @@ def unet_plan(cfg: SdConfig):
     return down, mid, up
 
 
+def unet_gflop(cfg: SdConfig, h: int, w: int, tc: int = 77) -> float:
+    """Algorithmic GFLOP of ONE UNet evaluation of ONE sample at h x w latents (2 per multiply-add; the prompt's k|v projections are
+    per-conditioning work and not counted): convolutions, linears and the attention products."""
+    fl = 0.0
+    down, mid, up = unet_plan(cfg)
+    hh, ww = h, w
+    fl += 2.0 * hh * ww * cfg.in_channels * cfg.block_out[0] * 9 + 2.0 * hh * ww * cfg.block_out[0] * cfg.out_channels * 9
+    ted = 4 * cfg.block_out[0]
+    fl += 2.0 * (cfg.block_out[0] * ted + ted * ted)
+    for blk in down + [mid] + up:
+        for l in blk:
+            if l[0] == "res":
+                _, _, ci, co, _ = l
+                fl += 2.0 * hh * ww * (ci * co * 9 + co * co * 9 + (ci * co if ci != co else 0)) + 2.0 * ted * co
+            elif l[0] == "attn":
+                c, t = l[2], hh * ww
+                fl += 2.0 * t * c * c * (2 + 3 + 1 + 1 + 1 + 8 + 4) + 4.0 * t * t * c + 4.0 * t * tc * c
+            elif l[0] == "down":
+                hh, ww = hh // 2, ww // 2
+                fl += 2.0 * hh * ww * l[2] * l[2] * 9
+            else:
+                hh, ww = hh * 2, ww * 2
+                fl += 2.0 * hh * ww * l[2] * l[2] * 9
+    return fl / 1e9
+
+
 def unet_state_dict_shapes(cfg: SdConfig) -> Dict[str, Tuple[int, ...]]:
     sh, ted = _Shapes(), 4 * cfg.block_out[0]
     sh.lin("time_embedding.linear_1", ted, cfg.block_out[0]); sh.lin("time_embedding.linear_2", ted, ted)
