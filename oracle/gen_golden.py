@@ -418,6 +418,47 @@ def gen_clip_text():
         save(f"clip_text_hf_{tag}_{'quickgelu' if quick else 'gelu'}", ids=ids, hidden=o.last_hidden_state, pooled=o.text_embeds)
 
 
+def gen_clip_hf_model():
+    """transformers' CLIPModel (both towers, one config object, no download) loaded DIRECTLY with transformers-named synthetic weights:
+    the fixture for models.TransformersOpenAICLIP, whose state dict uses those names (models/transformers_openai_clip.py:58-68)."""
+    hidden = {k: sys.modules.pop(k) for k in [k for k in sys.modules if k == "torchvision" or k.startswith("torchvision.")]}
+    try:
+        from transformers import CLIPConfig, CLIPModel, CLIPTextConfig, CLIPVisionConfig
+    finally:
+        sys.modules.update(hidden)
+    rz = R.ref("transforms.resize.resize_right")
+    from oracle.clip_vit import CLIP_MEAN, CLIP_STD
+    from perceptor_amd.engine.text import hf_text_state_dict_shapes
+    from perceptor_amd.engine.vit import hf_vision_state_dict_shapes
+    from perceptor_amd.utils.synth import synth_state_dict
+    vcfg, tcfg = (32, 8, 64, 2, 1, 32), (16, 96, 64, 2, 1, 32)
+    vc = CLIPVisionConfig(hidden_size=64, intermediate_size=256, num_hidden_layers=2, num_attention_heads=1, image_size=32, patch_size=8,
+                          projection_dim=32, hidden_act="quick_gelu", layer_norm_eps=1e-5)
+    tc = CLIPTextConfig(vocab_size=96, hidden_size=64, intermediate_size=256, num_hidden_layers=2, num_attention_heads=1,
+                        max_position_embeddings=16, projection_dim=32, hidden_act="quick_gelu", layer_norm_eps=1e-5, eos_token_id=95,
+                        bos_token_id=94, pad_token_id=0)
+    cfg = CLIPConfig(text_config=tc.to_dict(), vision_config=vc.to_dict(), projection_dim=32)
+    cfg._attn_implementation = "eager"
+    m = CLIPModel(cfg).eval()
+    sd = synth_state_dict({**hf_vision_state_dict_shapes(vcfg), **hf_text_state_dict_shapes(tcfg)}, 0)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all("position_ids" in k or k == "logit_scale" for k in missing), (missing, unexpected)
+    img = (seeded_noise((2, 3, 40, 40), 52) * 0.25 + 0.5).requires_grad_(True)
+    mean, std = torch.tensor(CLIP_MEAN)[None, :, None, None], torch.tensor(CLIP_STD)[None, :, None, None]
+    vo = m.vision_model(pixel_values=(rz.resize(img, out_shape=(32, 32)) - mean) / std)
+    ie = m.visual_projection(vo.pooler_output)
+    ids = _text_ids(3, 16, 96, 63)
+    with torch.no_grad():
+        to = m.text_model(input_ids=ids)
+        te = m.text_projection(to.pooler_output)
+    ien, ten = torch.nn.functional.normalize(ie), torch.nn.functional.normalize(te)
+    dist = (ten[:, None] - ien[None, :]).norm(dim=2).div(2).arcsin().square().mul(2)
+    (g,) = torch.autograd.grad(dist.mean(), img)
+    save("clip_hf_model_tiny", img=img.detach(), ids=ids, image_embeds=ie.detach(), image_hidden=vo.last_hidden_state.detach(),
+         image_pooler=vo.pooler_output.detach(), text_embeds=te, text_hidden=to.last_hidden_state, text_pooler=to.pooler_output,
+         distance=dist.detach(), grad=g)
+
+
 TOKENIZER_PROMPTS = [
     "a photograph of a playful cat", "painting of a dog", "", "  Hello,   World!  it's 2023 -- don't panic...",
     "An astronaut riding a horse on Mars; 4k, trending on artstation (highly detailed)", "fish &amp; chips &lt;3 #tasty @home 100% / 50$",

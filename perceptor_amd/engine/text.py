@@ -66,6 +66,25 @@ def from_hf_text_state_dict(hf: Dict[str, torch.Tensor]) -> Dict[str, torch.Tens
     return out
 
 
+def hf_text_state_dict_shapes(cfg, projection: bool = True) -> Dict[str, Tuple[int, ...]]:
+    """The text tower under transformers' key names (CLIPTextModel[WithProjection])."""
+    ctx, vocab, width, layers, heads, out = cfg
+    S = {"text_model.embeddings.token_embedding.weight": (vocab, width), "text_model.embeddings.position_embedding.weight": (ctx, width),
+         "text_model.final_layer_norm.weight": (width,), "text_model.final_layer_norm.bias": (width,)}
+    if projection:
+        S["text_projection.weight"] = (out, width)
+    for i in range(layers):
+        a = f"text_model.encoder.layers.{i}."
+        for n in "qkvo":
+            nm = "out_proj" if n == "o" else f"{n}_proj"
+            S[a + f"self_attn.{nm}.weight"] = (width, width); S[a + f"self_attn.{nm}.bias"] = (width,)
+        for nm in ("layer_norm1", "layer_norm2"):
+            S[a + nm + ".weight"] = (width,); S[a + nm + ".bias"] = (width,)
+        S[a + "mlp.fc1.weight"] = (4 * width, width); S[a + "mlp.fc1.bias"] = (4 * width,)
+        S[a + "mlp.fc2.weight"] = (width, 4 * width); S[a + "mlp.fc2.bias"] = (width,)
+    return S
+
+
 class TextEngine:
     def __init__(self, cfg, state_dict, device, dtype="bf16", quick_gelu=True):
         self.cfg, self.device = cfg, torch.device(device)

@@ -53,6 +53,46 @@ def vit_state_dict_shapes(cfg) -> Dict[str, Tuple[int, ...]]:
     return S
 
 
+def from_hf_vision_state_dict(hf: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """transformers' CLIPModel / CLIPVisionModelWithProjection keys (``vision_model.encoder.layers.{i}.self_attn.q_proj...``,
+    ``visual_projection.weight``; the form models/transformers_openai_clip.py:58-65 holds) -> the OpenAI-CLIP names this engine packs."""
+    g = lambda k: hf[k].detach().float()
+    out = {"class_embedding": g("vision_model.embeddings.class_embedding"), "conv1.weight": g("vision_model.embeddings.patch_embedding.weight"),
+           "positional_embedding": g("vision_model.embeddings.position_embedding.weight"),
+           "ln_pre.weight": g("vision_model.pre_layrnorm.weight"), "ln_pre.bias": g("vision_model.pre_layrnorm.bias"),
+           "ln_post.weight": g("vision_model.post_layernorm.weight"), "ln_post.bias": g("vision_model.post_layernorm.bias"),
+           "proj": g("visual_projection.weight").t().contiguous()}
+    i = 0
+    while f"vision_model.encoder.layers.{i}.layer_norm1.weight" in hf:
+        a, b = f"vision_model.encoder.layers.{i}.", f"transformer.resblocks.{i}."
+        out[b + "attn.in_proj_weight"] = torch.cat([g(a + f"self_attn.{n}_proj.weight") for n in "qkv"], dim=0)
+        out[b + "attn.in_proj_bias"] = torch.cat([g(a + f"self_attn.{n}_proj.bias") for n in "qkv"], dim=0)
+        for src, dst in (("self_attn.out_proj", "attn.out_proj"), ("layer_norm1", "ln_1"), ("layer_norm2", "ln_2"),
+                         ("mlp.fc1", "mlp.c_fc"), ("mlp.fc2", "mlp.c_proj")):
+            out[b + dst + ".weight"], out[b + dst + ".bias"] = g(a + src + ".weight"), g(a + src + ".bias")
+        i += 1
+    return out
+
+
+def hf_vision_state_dict_shapes(cfg) -> Dict[str, Tuple[int, ...]]:
+    """The same tower under transformers' key names (what ``TransformersOpenAICLIP.state_dict()`` holds)."""
+    res, patch, width, layers, heads, out = cfg
+    S = {"vision_model.embeddings.class_embedding": (width,), "vision_model.embeddings.patch_embedding.weight": (width, 3, patch, patch),
+         "vision_model.embeddings.position_embedding.weight": ((res // patch) ** 2 + 1, width),
+         "vision_model.pre_layrnorm.weight": (width,), "vision_model.pre_layrnorm.bias": (width,),
+         "vision_model.post_layernorm.weight": (width,), "vision_model.post_layernorm.bias": (width,), "visual_projection.weight": (out, width)}
+    for i in range(layers):
+        a = f"vision_model.encoder.layers.{i}."
+        for n in "qkvo":
+            nm = "out_proj" if n == "o" else f"{n}_proj"
+            S[a + f"self_attn.{nm}.weight"] = (width, width); S[a + f"self_attn.{nm}.bias"] = (width,)
+        for nm in ("layer_norm1", "layer_norm2"):
+            S[a + nm + ".weight"] = (width,); S[a + nm + ".bias"] = (width,)
+        S[a + "mlp.fc1.weight"] = (4 * width, width); S[a + "mlp.fc1.bias"] = (4 * width,)
+        S[a + "mlp.fc2.weight"] = (width, 4 * width); S[a + "mlp.fc2.bias"] = (width,)
+    return S
+
+
 class _Lin:
     """Forward weights + the transposed copy used by the input-gradient GEMM."""
 
@@ -122,8 +162,9 @@ class VitEngine:
 
     # ---- forward --------------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward(self, images: torch.Tensor, save: bool = False) -> torch.Tensor:
-        """images NCHW fp32 in [0,1] (any size) -> un-normalised embeddings [N, out_dim] fp32."""
+    def forward(self, images: torch.Tensor, save: bool = False, features: bool = False):
+        """images NCHW fp32 in [0,1] (any size) -> un-normalised embeddings [N, out_dim] fp32
+        (features=True: also the last hidden state [N, T, width] and the post-LayerNorm class token [N, width], both fp32)."""
         if not images.is_cuda:
             raise RuntimeError("VitEngine runs on a HIP device only (no CPU fallback)")
         res, patch, width, layers, heads, out = self.cfg
@@ -179,12 +220,13 @@ class VitEngine:
                 sv["layers"].append(dict(x_in=x, mr1=mr1, qkv=qkv if not fused else None, p=p, aws=aws, lse=lse, a=a if fused else None,
                                          x_mid=x_mid, mr2=mr2, hpre=hpre))
             x = x_out
-        y16, _, mr_post = self._ln(x, t * width, self.ln_post, n, width)         # cls token rows only
+        y16, y32, mr_post = self._ln(x, t * width, self.ln_post, n, width, want32=features)         # cls token rows only
         emb = ops.igemm(y16, self.proj.fwd, out_f32=True)
         if save:
             sv.update(x_final=x, mr_post=mr_post)
             self.saved = sv
-        return emb[:, :out] if emb.shape[1] != out else emb
+        emb = emb[:, :out] if emb.shape[1] != out else emb
+        return (emb, x.view(n, t, width), y32) if features else emb
 
     # ---- input gradient -----------------------------------------------------------------------------------
     @torch.no_grad()

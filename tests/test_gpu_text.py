@@ -74,3 +74,28 @@ def test_encode_texts_strings_and_errors():
         m.text.forward(torch.full((1, 4), 9999, dtype=torch.int64))
     with pytest.raises(RuntimeError):
         models.OpenCLIP("tiny", "synthetic", config=TINY_VIT).to("cuda").encode_tokens(ids)     # no text_config: no text tower
+
+
+def test_transformers_openai_clip_surface_vs_clipmodel_fixture():
+    """models.TransformersOpenAICLIP (transformers-named state dict) against transformers' CLIPModel on the same weights: features,
+    encodings, spherical distance and the image gradient through it (models/transformers_openai_clip.py:88-134, tests :140-152)."""
+    from perceptor_amd import models
+    g = golden("clip_hf_model_tiny")
+    m = models.TransformersOpenAICLIP(config=(32, 8, 64, 2, 1, 32), text_config=(16, 96, 64, 2, 1, 32)).to("cuda")
+    assert "vision_model.encoder.layers.1.self_attn.q_proj.weight" in m.state_dict() and "text_projection.weight" in m.state_dict()
+    with torch.no_grad():
+        ie = m.encode_images(g["img"])
+        te = m.encode_token_ids(g["ids"])
+    assert _rel(ie.unnormalized_encodings.cpu(), g["image_embeds"]) < 1e-2 and _rel(te.unnormalized_encodings.cpu(), g["text_embeds"]) < 1e-2
+    assert _rel(ie.features.last_hidden_state.cpu(), g["image_hidden"]) < 1e-2 and _rel(ie.features.pooler_output.cpu(), g["image_pooler"]) < 1e-2
+    assert _rel(te.features.last_hidden_state.cpu(), g["text_hidden"]) < 1e-2 and _rel(te.features.pooler_output.cpu(), g["text_pooler"]) < 1e-2
+    assert float((ie.encodings.norm(dim=1) - 1).abs().max()) < 1e-5
+    d = m.spherical_distance(te, ie)
+    assert float((d.cpu() - g["distance"]).abs().max()) < 2e-2 * float(g["distance"].abs().max())
+    img = g["img"].cuda().requires_grad_(True)
+    with torch.enable_grad():
+        m.spherical_distance(te, m.encode_images(img)).mean().backward()
+    cos = torch.nn.functional.cosine_similarity(img.grad.cpu().double().flatten(), g["grad"].double().flatten(), dim=0)
+    assert float(cos) > 0.999 and _rel(img.grad.cpu(), g["grad"]) < 3e-2
+    with pytest.raises(NotImplementedError):
+        models.TransformersOpenAICLIP("M-CLIP/XLM-Roberta-Large-Vit-L-14")

@@ -228,3 +228,20 @@ def test_text_tower_vs_reference_and_transformers(fixture, tag, quick):
     assert float((pooled - g["pooled"]).abs().max()) < 2e-5 * (1 + float(g["pooled"].abs().max()))
     if "hidden" in g:
         assert float((hidden - g["hidden"]).abs().max()) < 2e-5 * (1 + float(g["hidden"].abs().max()))
+
+
+def test_transformers_key_mapping_against_clipmodel_fixture():
+    """engine.vit.from_hf_vision_state_dict / engine.text.from_hf_text_state_dict (host logic: transformers -> OpenAI-CLIP key names) +
+    the oracle towers reproduce what transformers' CLIPModel computed from the SAME transformers-named weights (gen_clip_hf_model)."""
+    from oracle import clip_text
+    from perceptor_amd.engine.text import from_hf_text_state_dict, hf_text_state_dict_shapes
+    from perceptor_amd.engine.vit import from_hf_vision_state_dict, hf_vision_state_dict_shapes
+    g = golden("clip_hf_model_tiny")
+    vcfg, tcfg = (32, 8, 64, 2, 1, 32), (16, 96, 64, 2, 1, 32)
+    sd = synth_state_dict({**hf_vision_state_dict_shapes(vcfg), **hf_text_state_dict_shapes(tcfg)}, 0)
+    with torch.no_grad():
+        ie = clip_vit.encode_images(from_hf_vision_state_dict(sd), vcfg, g["img"], True, normalize=False)
+        hidden, te = clip_text.text_forward(from_hf_text_state_dict(sd), tcfg, g["ids"], True)
+    assert float((ie - g["image_embeds"]).abs().max()) < 2e-5 * (1 + float(g["image_embeds"].abs().max()))
+    assert float((te - g["text_embeds"]).abs().max()) < 2e-5 * (1 + float(g["text_embeds"].abs().max()))
+    assert float((hidden - g["text_hidden"]).abs().max()) < 2e-5 * (1 + float(g["text_hidden"].abs().max()))
