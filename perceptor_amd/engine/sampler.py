@@ -15,6 +15,8 @@ def _prep(t: torch.Tensor) -> torch.Tensor:
 
 
 def _vec(v: torch.Tensor, n: int, device) -> torch.Tensor:
+    if not torch.is_tensor(v):          # a Python scalar: a device-side fill (a host-to-device copy is not capturable in a HIP graph)
+        return torch.full((n,), float(v), dtype=torch.float32, device=device)
     v = torch.as_tensor(v, dtype=torch.float32, device=device).reshape(-1)
     if v.numel() == 1 and n > 1:
         v = v.expand(n)
