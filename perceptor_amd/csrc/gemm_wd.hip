@@ -37,13 +37,13 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
 #define GSTAMP(k) do {} while (0)
 #endif
   GSTAMP(0);
-  const int tiles_n = a.N / BN, tiles_m = (a.M + TM - 1) / TM;
+  const int tiles_n = (a.N + BN - 1) / BN, tiles_m = (a.M + TM - 1) / TM;   // N a multiple of 32: the last tile's waves past N multiply zeros and store nothing
   const int logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
   // every XCD (own 4 MB L2) gets a contiguous range of tiles: let it walk ALL tiles of the smaller operand for a few of the larger
   const bool mfast = (int64_t)a.M <= (int64_t)a.N;
   const int tm = mfast ? logical % tiles_m : logical / tiles_n, tn = mfast ? logical / tiles_m : logical % tiles_n;
   const int m0 = tm * TM, n0 = tn * BN;
-  const int nch_all = a.K / BK;
+  const int nch_all = (a.K + BK - 1) / BK;          // the packed weights are zero-padded to whole 128-deep chunks
   int c0 = 0, nch = nch_all;
   if (a.splitk > 1) {
     const int per = (nch_all + a.splitk - 1) / a.splitk;
@@ -62,7 +62,8 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
   }
   // this wave's weight stream: [chunk][k32 (4)][16-column block (2)][lane][8], 8 KB per chunk, contiguous
   const int64_t wslab = (int64_t)nch_all * 8192;
-  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc((const char*)a.Bf + (int64_t)(tn * 8 + wid) * wslab, wslab);
+  const bool wave_live = n0 + wid * 32 < a.N;          // wave-uniform; a dead wave's weight resource is empty (every load returns zeros)
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc((const char*)a.Bf + (wave_live ? (int64_t)(tn * 8 + wid) * wslab : 0), wave_live ? wslab : 0);
   const uint32_t wvo = (uint32_t)lane * 16u + (uint32_t)c0 * 8192u;
 
   uint4 pr[NPI];
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
       for (int cb = 0; cb < 2; ++cb) {
         const int nl = wid * 32 + cb * 16 + 4 * (lane >> 4);
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias) bv = *(const float4*)(a.bias + n0 + nl);
+        if (a.bias && wave_live) bv = *(const float4*)(a.bias + n0 + nl);
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
           const f32x4 c = acc[mb][cb];
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
       const int r = prow + 16 * j, m = m0 + r;
-      if (m >= a.M) continue;
+      if (m >= a.M || n0 + pc8 * 8 >= a.N) continue;
       uint4 v = *(const uint4*)(smem + r * HROW + pc8 * 16);
       if (a.R || a.aux) {
         float f[8], rr[8];
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
     const int n = n0 + wid * 32 + cb * 16 + 4 * (lane >> 4);
+    if (!wave_live) continue;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!raw && a.bias) bv = *(const float4*)(a.bias + n);
 #pragma unroll
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
 template <typename T>
 int launch(const pmi_igemm_args& a, hipStream_t s, int mb) {
   const int tm = 16 * mb;
-  const dim3 grid(((a.M + tm - 1) / tm) * (a.N / 256), 1, a.splitk > 1 ? a.splitk : 1);
+  const dim3 grid(((a.M + tm - 1) / tm) * ((a.N + 255) / 256), 1, a.splitk > 1 ? a.splitk : 1);
   if (mb == 9) hipLaunchKernelGGL((gemm_wd_kernel<T, 9>), grid, dim3(512), 0, s, a);
   else hipLaunchKernelGGL((gemm_wd_kernel<T, 8>), grid, dim3(512), 0, s, a);
   PMI_CHECK_LAUNCH();
@@ -259,7 +261,7 @@ int pmi_gemm_wd_tile_rows(const pmi_igemm_args* a, int splitk) {
   int best = 8;
   long best_cost = -1;
   for (int mb = 8; mb <= 9; ++mb) {
-    const long wgs = (long)((a->M + 16 * mb - 1) / (16 * mb)) * (a->N / 256) * (splitk > 1 ? splitk : 1);
+    const long wgs = (long)((a->M + 16 * mb - 1) / (16 * mb)) * ((a->N + 255) / 256) * (splitk > 1 ? splitk : 1);
     const long cost = ((wgs + 255) / 256) * mb;
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = mb; }
   }
@@ -270,8 +272,8 @@ int pmi_gemm_wd_tile_rows(const pmi_igemm_args* a, int splitk) {
 extern "C" int pmi_gemm_wd_eligible(const pmi_igemm_args* a) {
   if (!a->Bf || a->taps != 1 || a->up || a->stride != 1 || a->batch > 1 || a->C1 != 0 || a->A1) return 0;
   if (a->nbias || a->stats || a->pro_a || a->res_up || a->split_out) return 0;
-  if ((a->K % 128) || (a->N % 256) || a->K != a->C0 || a->M < 64) return 0;
-  if (a->R && a->res_f32 && !a->out_f32) return 0;
+  if ((a->K % 32) || (a->N % 32) || a->K != a->C0 || a->M < 64) return 0;      // K tail: zero-padded weights; N tail: masked waves
+  if ((a->N % 256) && (a->N % 256) < 128 && a->N < 1024) return 0;            // a last tile less than half full on a narrow matrix: the generic 128-wide tiles waste less
   if ((a->D2 || a->aux) && (a->out_f32 || a->splitk > 1 || (a->R && a->res_f32))) return 0;
   return 1;
 }

@@ -118,8 +118,13 @@ class PackedLinear:
         """Fragment order for the weights-direct GEMM (csrc/gemm_wd.hip), 16x16x32 MFMA:
         [N/32][K/128][32-deep k-step (4)][16-column block (2)][lane = 16*(k quarter) + column][8 k]."""
         if "gemm" not in self._frag:
-            assert self.taps == 1 and self.n_p % 32 == 0 and self.K % 128 == 0
-            w = self.w.view(self.n_p // 32, 2, 16, self.K // 128, 4, 4, 8)     # nb, cb, r16, chunk, k32, q4, j
+            assert self.taps == 1 and self.n_p % 32 == 0 and self.K % 32 == 0
+            kp = (self.K + 127) // 128 * 128                                    # K tail: zero weights up to a whole 128-deep chunk
+            w = self.w
+            if kp != self.K:
+                w = torch.zeros((self.n_p, kp), dtype=self.w.dtype, device=self.w.device)
+                w[:, :self.K] = self.w
+            w = w.view(self.n_p // 32, 2, 16, kp // 128, 4, 4, 8)              # nb, cb, r16, chunk, k32, q4, j
             self._frag["gemm"] = w.permute(0, 3, 4, 1, 5, 2, 6).contiguous()
         return self._frag["gemm"]
 
@@ -201,11 +206,12 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
         cfg = _hip.lib().pmi_conv3x3_halo_config(C.byref(a))
         a.pro_a = None
         a.Bf = ptr(lin.frag16(64)) if cfg == 6 else ptr(lin.frag16(32)) if cfg == 7 else ptr(lin.frag(64)) if cfg == 4 else None
-    if GEMM_WD_ENABLED and lin.taps == 1 and not lin.split and not up and stride == 1 and a1 is None and lin.n_p % 256 == 0 and lin.K % 128 == 0 \
-            and nbias is None and not want_stats and prologue is None:
-        a.Bf = ptr(lin.frag_gemm())            # plain GEMM: weights-direct kernel (csrc/gemm_wd.hip)
     if pre_out is not None or act_grad_of is not None:
         a.D2, a.aux, a.aux_act = ptr(pre_out), ptr(act_grad_of), act_grad
+    if GEMM_WD_ENABLED and lin.taps == 1 and not lin.split and not up and stride == 1 and a1 is None and lin.n_p % 32 == 0 and lin.K % 32 == 0 \
+            and nbias is None and not want_stats and prologue is None:
+        a.Bf = 1                               # plain GEMM: ask whether the weights-direct kernel (csrc/gemm_wd.hip) takes this shape ...
+        a.Bf = ptr(lin.frag_gemm()) if _hip.lib().pmi_gemm_wd_eligible(C.byref(a)) else None      # ... and only then pack its weight order
     if prologue is not None:
         ca, cb, pact = prologue
         if HALO_ENABLED and not lin.split and _hip.lib().pmi_conv3x3_halo_config(C.byref(a)) >= 0:

@@ -150,6 +150,11 @@ def test_igemm_linear_ragged_and_nbias(dtype):
     dict(m=300, k=256, n=256, res="16"),                          # ragged last tile, 16-bit residual
     dict(m=8192, k=512, n=1536),                                  # UNet attention qkv at 32x32
     dict(m=72, k=128, n=512, f32=True, bias=False),
+    dict(m=4096, k=320, n=2560),                                  # SD level-0 GEGLU projection: K tail (320 = 2.5 chunks of 128)
+    dict(m=4096, k=320, n=960, res="16"),                         # N tail: 960 = 3.75 tiles of 256, the last tile's two dead waves store nothing
+    dict(m=1000, k=640, n=1920, act=3),                           # both tails, ragged rows
+    dict(m=2048, k=2560, n=640, res="f32"),                       # fp32 residual, 16-bit out (the transformer blocks' last feed-forward GEMM), N tail
+    dict(m=333, k=1280, n=1184, f32=True, res="f32"),             # N = 37 blocks of 32, fp32 out
 ])
 def test_gemm_wd(case, dtype):
     """Weights-direct GEMM (csrc/gemm_wd.hip) against fp32 torch on operands pre-rounded to the compute type."""
