@@ -445,7 +445,15 @@ extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
   }
   // config 3: at most 32 output channels (the UNet's last conv, 128 -> 6): one MFMA block column per wave
   if (a->N <= 32 && (a->N % 4) == 0 && !a->stats && !a->res_up && a->M / (a->H * a->W) * (a->H / 8) * (a->W / 32) >= 256) return 3;
-  if ((a->N % 128) || a->out_f32 || (a->R && a->res_f32)) return -1;
+  if (a->out_f32 || (a->R && a->res_f32)) return -1;
+  if (a->N % 128) {
+    // Cout a multiple of 32 but not of 128 (StableDiffusion's 320-channel level): the 128-channel weights-direct tiles with a masked tail
+    // tile, where the grid still fills the chip and the tail tile is at least half full
+    const int t8 = a->M / (a->H * a->W) * (a->H / 8) * (a->W / 32);
+    const bool ok7t = a->Bf && g_wd && g_wd_mf16 && (a->N % 32) == 0 && (a->N % 128) >= 64 && a->N > 128 && (!a->pro_a || a->C0 + a->C1 <= 1024);
+    if (g_force_cfg == 7) return ok7t ? 7 : -1;
+    return (g_force_cfg < 0 && g_wd128 && ok7t && t8 * ((a->N + 127) / 128) >= 256) ? 7 : -1;
+  }
   if (a->Bf && g_wd && (!a->pro_a || a->C0 + a->C1 <= 2048)) {   // weights-direct kernel (its prologue coefficient table holds 2048 channels): 4 / 6 = 256-channel tiles (64-channel chunks), 7 = 128-channel tiles (32-channel chunks)
     const int t8 = a->M / (a->H * a->W) * (a->H / 8) * (a->W / 32);
     const bool ok4 = (a->N % 256) == 0;

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
   const int l31 = lane & 31, lhi = lane >> 5;
   const int wn = wid;
 
-  const int tiles_x = a.W / 32, tiles_y = a.H / 8, tiles_n = a.N / BN;
+  const int tiles_x = a.W / 32, tiles_y = a.H / 8, tiles_n = (a.N + BN - 1) / BN;   // Cout a multiple of 32: the last tile's waves past Cout multiply zeros and store nothing
   const int nimg = a.M / (a.H * a.W);
   int logical = xcd_remap(blockIdx.x, nimg * tiles_y * tiles_x * tiles_n);
   const int tn = logical % tiles_n; logical /= tiles_n;
@@ -104,7 +104,8 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
   const int64_t bytes1 = a.A1 ? ((img_px - 1) * a.lda1 + a.C1) * 2 : 0;
   // this wave's weight stream: [chunk][dx][step][dy](x [16-channel block])[lane][8] 16-bit, contiguous in loop order
   const int64_t wslab = (int64_t)nchunks * WGC * GB;
-  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc((const char*)a.Bf + (int64_t)(tn * NWN + wn) * wslab, wslab);
+  const bool wave_live = n0 + wn * 32 < a.N;           // wave-uniform; a dead wave's weight resource is empty (every load returns zeros)
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc((const char*)a.Bf + (wave_live ? (int64_t)(tn * NWN + wn) * wslab : 0), wave_live ? wslab : 0);
   const uint32_t wvo = (uint32_t)lane * 16u;
 
   // ---- staging plan: source pixel (inside the image) per staged piece, -1 = zero padding; lives in LDS ([piece][thread]:
@@ -347,8 +348,10 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
   for (int c = tid; c < BN; c += NT) {
     const int n = n0 + c;
     float b = 0.f;
-    if (a.bias) b = a.bias[n];
-    if (a.nbias) b += a.nbias[(int64_t)img * (a.ldnb ? a.ldnb : a.N) + n];
+    if (n < a.N) {
+      if (a.bias) b = a.bias[n];
+      if (a.nbias) b += a.nbias[(int64_t)img * (a.ldnb ? a.ldnb : a.N) + n];
+    }
     bsm[c] = b;
   }
   constexpr int LPR = BN / 8;                          // lanes per output pixel row (16 bytes each): 32 / 16
@@ -357,13 +360,14 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
   constexpr int NWI = PXW / PPI;                       // store instructions per wave (16)
   const int q = lane % LPR, psub = lane / LPR;
   const int cl0 = q * 8;
+  const bool col_live = n0 + cl0 < a.N;                // this lane's 8 output channels exist (Cout tail of the last tile)
   uint4 rres[NWI];
 #pragma unroll
   for (int t = 0; t < NWI; ++t) {                      // residual loads fly while the accumulators are staged
     const int p = wid * PXW + t * PPI + psub;
     const int y = y0 + (p >> 5), x = x0 + (p & 31);
     rres[t] = make_uint4(0, 0, 0, 0);
-    if (a.R) {
+    if (a.R && col_live) {
       const int64_t rr = a.res_up ? (((int64_t)img * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.ldr
                                   : (((int64_t)img * a.H + y) * a.W + x) * a.ldr;
       rres[t] = *(const uint4*)((const u16*)a.R + rr + n0 + cl0);
@@ -432,7 +436,7 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
       for (int e = 0; e < 8; ++e) { cs[e] += f[e]; cs[8 + e] += f[e] * f[e]; }
     }
     const int y = y0 + (p >> 5), x = x0 + (p & 31);
-    *(uint4*)((u16*)a.D + (((int64_t)img * a.H + y) * a.W + x) * a.ldd + n0 + cl0) = v;
+    if (col_live) *(uint4*)((u16*)a.D + (((int64_t)img * a.H + y) * a.W + x) * a.ldd + n0 + cl0) = v;
   }
   STAMP(7);
   if (a.stats) {
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) v += stat[w * 2 * BN + c];
-      o[c] = v;
+      if (n0 + (c >> 1) < a.N) o[c] = v;
     }
   }
 #ifdef PMI_STAMPS
@@ -481,7 +485,7 @@ int launch_p(const pmi_igemm_args& a, hipStream_t s, int cfg) {
   }
   if (a.split_out) return PMI_ERR_ARG;
   if (cfg == 7) {                                      // 128-channel tiles, two 4-wave workgroups per CU
-    hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, true, 4, 32>), dim3(nimg * (a.H / 8) * (a.W / 32) * (a.N / 128)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, true, 4, 32>), dim3(nimg * (a.H / 8) * (a.W / 32) * ((a.N + 127) / 128)), dim3(256), 0, s, a);
     PMI_CHECK_LAUNCH();
     return PMI_OK;
   }

@@ -200,7 +200,7 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
     a.ldnb = nbias.stride(0) if nbias is not None else 0
     a.batch, a.batch_inner = 1, 1
     a.dtype = dt
-    if conv and lin.taps == 9 and stride == 1 and HALO_ENABLED and WD_ENABLED and lin.n_p % 128 == 0 and lin.cin_p % 64 == 0:
+    if conv and lin.taps == 9 and stride == 1 and HALO_ENABLED and WD_ENABLED and lin.n_p % 32 == 0 and lin.n_p >= 128 and lin.cin_p % 64 == 0:
         a.Bf = 1                       # ask which tile config the weights-direct kernel would run, then hand it that packing
         a.pro_a = 1 if (prologue is not None and not lin.split) else None     # (the table size limit depends on a fused prologue)
         cfg = _hip.lib().pmi_conv3x3_halo_config(C.byref(a))

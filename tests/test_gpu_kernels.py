@@ -70,6 +70,10 @@ def _check(got, ref, dtype, extra=1.0):
     dict(n=2, h=24, w=32, cin=64, cout=384, k=3, prologue=True, force_cfg=7),
     dict(n=1, h=8, w=32, cin=64, cout=128, k=3, up=True, force_cfg=7),
     dict(n=1, h=16, w=64, cin=128, cout=128, k=3, res_up=True, prologue=True, force_cfg=7),
+    dict(n=1, h=8, w=64, cin=128, cout=320, k=3, force_cfg=7),             # config 7 with a Cout tail: 320 = 2.5 tiles, two dead waves in the last one
+    dict(n=2, h=16, w=32, cin=192, cout=192, k=3, split=128, prologue=True, force_cfg=7),
+    dict(n=1, h=16, w=64, cin=128, cout=448, k=3, res_up=True, prologue=True, force_cfg=7),
+    dict(n=8, h=64, w=64, cin=320, cout=320, k=3, prologue=True),          # StableDiffusion level 0 (batch 8, 64x64 latents): picks the tail-tile config by itself
     dict(n=8, h=64, w=64, cin=64, cout=256, k=3, prologue=True),           # enough tiles for the halo kernel by itself
     dict(n=8, h=128, w=64, cin=64, cout=6, k=3, f32=True, prologue=True),  # last conv of the UNet: halo config 3 (<= 32 output channels), fp32 out
     dict(n=8, h=128, w=64, cin=128, cout=24, k=3),                         # config 3, 16-bit out with a 16-bit residual
@@ -300,7 +304,8 @@ def test_sampler_updates_match_golden():
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [dict(h=16, w=32, cin=64, cout=256, force_cfg=0), dict(h=32, w=32, cin=64, cout=128, force_cfg=1), dict(h=16, w=16, cin=64, cout=192),
                                   dict(h=16, w=64, cin=64, cout=256, force_cfg=4), dict(h=16, w=64, cin=64, cout=256, force_cfg=6),
-                                  dict(h=16, w=64, cin=64, cout=128, force_cfg=7), dict(h=8, w=16, cin=64, cout=64, k=1)])
+                                  dict(h=16, w=64, cin=64, cout=128, force_cfg=7), dict(h=16, w=64, cin=64, cout=320, force_cfg=7),
+                                  dict(h=8, w=16, cin=64, cout=64, k=1)])
 def test_fused_output_statistics_feed_groupnorm(case, dtype):
     """conv epilogue statistics (halo + generic kernels) -> GroupNorm coefficients == standalone statistics pass,
     also for a concat of two producers with a group that spans both."""
