@@ -463,7 +463,7 @@ extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
     // config 7: 128-channel tiles, 4 waves, 32-channel chunks, two workgroups per CU (its coefficient table holds 1024 channels)
     const bool ok7 = g_wd_mf16 && (!a->pro_a || a->C0 + a->C1 <= 1024);
     if (g_force_cfg == 7 && ok7) return 7;
-    if (g_force_cfg < 0 && g_wd128 && ok7 && !ok4 && t8 * (a->N / 128) >= 256) return 7;
+    if (g_force_cfg < 0 && g_wd128 && ok7 && !ok4 && t8 * (a->N / 128) >= (a->N > 512 ? 128 : 256)) return 7;   // (640-channel layers on 32x32 maps at batch 8: 160 tiles)
     // 256-multiple Cout on a map too small for the 256-channel tiles (32x32 at batch 8): the 128-channel tiles give twice the workgroups
     // and measure 5-10 % ahead of the halo kernel's 4-wave config there
     if (g_force_cfg < 0 && g_wd128 && ok7 && ok4 && t8 * (a->N / 128) >= 128) return 7;
