@@ -113,28 +113,33 @@ __global__ __launch_bounds__(64) void attn_flash_kernel(const u16* __restrict__ 
       float mx = -1e30f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float v = sacc[qt][r] * scale_log2e;
-        if (tail && sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi >= Tk) v = -1e30f;
-        sacc[qt][r] = v;
-        mx = fmaxf(mx, v);
+        if (tail && sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi >= Tk) sacc[qt][r] = -1e30f;
+        mx = fmaxf(mx, sacc[qt][r]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run[qt], mx);
-      const float alpha = exp2f(m_run[qt] - m_new);
+      mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale_log2e;              // the scale is positive: max commutes with it
+      // Lazy rescaling: the running maximum only follows when a block exceeds it by more than 2^8 (the probabilities then stay below
+      // 256: exact in fp32 sums, well inside the 16-bit operand range), so after the first blocks the accumulator rescale (one multiply per
+      // accumulator register) and its exp2 almost never run.  The branch is wave-uniform.
+      if (__any(mx > m_run[qt] + 8.f)) {
+        const float m_new = fmaxf(m_run[qt], mx);
+        const float alpha = exp2f(m_run[qt] - m_new);
+        l_run[qt] *= alpha;
+        m_run[qt] = m_new;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[qt][db][r] *= alpha;
+      }
+      const float mneg = -m_run[qt];
       float rs = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(sacc[qt][r] - m_new);
+        const float p = exp2f(fmaf(sacc[qt][r], scale_log2e, mneg));   // one fused multiply-add + one v_exp per score
         sacc[qt][r] = p;
         rs += p;
       }
       rs += __shfl_xor(rs, 32);
-      l_run[qt] = l_run[qt] * alpha + rs;
-      m_run[qt] = m_new;
-#pragma unroll
-      for (int db = 0; db < DB; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[qt][db][r] *= alpha;
+      l_run[qt] += rs;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         float pf[8];
@@ -170,12 +175,129 @@ __global__ __launch_bounds__(64) void attn_flash_kernel(const u16* __restrict__ 
   }
 }
 
-static int g_flash_qt = 0;       // A/B switch (pmi_set_option 9): 0 = automatic, 1 / 2 = query tiles per wave
+// The same computation with FOUR waves (128 queries) per workgroup sharing every K / V^T fragment through LDS: one wave per 32 queries
+// streams 7 KB (d = 40) per key block from L2, at T = 4096 that is 7 GB per call and 12 TB/s of L2 -> register traffic -- the bound
+// of the one-wave kernel.  Here the workgroup loads a key block's fragments once (register-staged, one block ahead, double-buffered in
+// LDS: one barrier per key block) and the four waves read them from LDS (fragment order: 64 lanes x 16 B contiguous, conflict-free).
+template <typename T_, int KQ, int DB>
+__global__ __launch_bounds__(256) void attn_flash_lds_kernel(const u16* __restrict__ qf, const u16* __restrict__ kf, const u16* __restrict__ vtf,
+                                                            u16* __restrict__ out, int T, int Tk, int heads, int d, float scale_log2e) {
+  constexpr int NP = KQ + 2 * DB;                      // 1 KB fragment pieces per key block
+  constexpr int NPI = (NP + 3) / 4;                    // pieces staged per thread
+  __shared__ uint4 kv[2][NP * 64];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nx = gridDim.x;
+  const int lin = xcd_remap(blockIdx.x + nx * blockIdx.y, nx * gridDim.y);
+  const int bh = lin / nx, bx = lin - bh * nx;
+  const int ntq = (T + 31) >> 5, ntk = (Tk + 31) >> 5;
+  const int tq = bx * 4 + wid;                         // this wave's query tile (past the end: repeats the last one, never stored)
+  uint4 qr[KQ];
+#pragma unroll
+  for (int kk = 0; kk < KQ; ++kk) qr[kk] = *(const uint4*)(qf + rfrag_g((int64_t)bh * ntq + min(tq, ntq - 1), KQ, kk, lhi, l31));
+  f32x16 o[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const u16* const kbase = kf + (int64_t)bh * ntk * KQ * 512;
+  const u16* const vbase = vtf + (int64_t)bh * ntk * 2 * DB * 512;
+  // piece p of key block sb: K fragment p (p < KQ) or V^T fragment p - KQ; thread (wave w, lane) stages pieces w, w + 4, ...
+  // (plain macros: as lambdas capturing the staging array the compiler demoted it to scratch)
+  uint4 st[NPI];
+#define FLASH_LOAD_BLOCK(SB)                                                                                              \
+  _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                                       \
+    const int p = wid + 4 * i;                                                                                            \
+    const u16* src = p < KQ ? kbase + ((int64_t)(SB) * KQ + p) * 512 : vbase + ((int64_t)(SB) * 2 * DB + (p - KQ)) * 512; \
+    st[i] = p < NP ? *(const uint4*)(src + lane * 8) : make_uint4(0, 0, 0, 0);                                            \
+  }
+#define FLASH_STORE_BLOCK(BUF)                                                                                            \
+  _Pragma("unroll") for (int i = 0; i < NPI; ++i) {                                                                       \
+    const int p = wid + 4 * i;                                                                                            \
+    if (p < NP) kv[BUF][p * 64 + lane] = st[i];                                                                           \
+  }
+  FLASH_LOAD_BLOCK(0)
+  FLASH_STORE_BLOCK(0)
+  if (ntk > 1) { FLASH_LOAD_BLOCK(1) }
+  __syncthreads();
+  for (int sb = 0; sb < ntk; ++sb) {
+    const uint4* const cur = kv[sb & 1];
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) sacc = T_::mfma32(cur[kk * 64 + lane], qr[kk], sacc);
+    const bool tail = (sb + 1) * 32 > Tk;
+    float mx = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (tail && sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi >= Tk) sacc[r] = -1e30f;
+      mx = fmaxf(mx, sacc[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32)) * scale_log2e;
+    if (__any(mx > m_run + 8.f)) {                     // lazy rescaling, as in attn_flash_kernel
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f(m_run - m_new);
+      l_run *= alpha;
+      m_run = m_new;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
+    const float mneg = -m_run;
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = exp2f(fmaf(sacc[r], scale_log2e, mneg));
+      sacc[r] = p;
+      rs += p;
+    }
+    rs += __shfl_xor(rs, 32);
+    l_run += rs;
+    // the next block's fragments (in flight since the previous iteration) go to the other buffer: every wave finished reading it before
+    // the barrier that ended the previous iteration
+    if (sb + 1 < ntk) { FLASH_STORE_BLOCK((sb + 1) & 1) }
+    if (sb + 2 < ntk) { FLASH_LOAD_BLOCK(sb + 2) }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      float pf[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = sacc[8 * ks + j];
+      const uint4 pfrag = pack8<T_>(pf);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) o[db] = T_::mfma32(cur[(KQ + ks * DB + db) * 64 + lane], pfrag, o[db]);
+    }
+    __syncthreads();
+  }
+  const int t = tq * 32 + l31;
+  if (tq >= ntq || t >= T) return;
+  const int n = bh / heads, h = bh - n * heads;
+  const float inv = 1.f / l_run;
+  u16* ob = out + ((int64_t)n * T + t) * (heads * d) + h * d;
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 32 * db + 8 * g + 4 * lhi;
+      if (c < d) *(uint2*)(ob + c) = pack4<T_>(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+    }
+#undef FLASH_LOAD_BLOCK
+#undef FLASH_STORE_BLOCK
+}
+
+static int g_flash_qt = 0;       // A/B switch (pmi_set_option 9): 0 = automatic (LDS-shared kernel for long sequences), 1 / 2 = one-wave kernel with 1 / 2 query tiles per wave
 
 template <typename T_, int KQ, int DB>
 void launch_flash(const u16* qf, const u16* kf, const u16* vtf, u16* out, int N, int T, int Tk, int heads, int d, float sl2, hipStream_t st) {
   const int ntq = (T + 31) / 32;
   // two query tiles per wave where the sequence is long enough to still fill the chip (and the accumulators fit: DB <= 3)
+  if (g_flash_qt != 1 && g_flash_qt != 2 && ntq >= 64) {     // long query sequences (T >= 2048): four waves per workgroup share K / V^T through LDS (0.61 vs 0.65 ms at T = 4096)
+    hipLaunchKernelGGL((attn_flash_lds_kernel<T_, KQ, DB>), dim3((ntq + 3) / 4, N * heads), dim3(256), 0, st, qf, kf, vtf, out, T, Tk, heads, d, sl2);
+    return;
+  }
   if constexpr (DB <= 2) {
     if (g_flash_qt == 2) {      // measured at T = 4096, d = 40: 0.85 ms against 0.65 ms with one tile per wave (204 VGPRs: one wave per SIMD)
       hipLaunchKernelGGL((attn_flash_kernel<T_, KQ, DB, 2>), dim3((ntq + 1) / 2, N * heads), dim3(64), 0, st, qf, kf, vtf, out, T, Tk, heads, d, sl2);

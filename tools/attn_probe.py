@@ -34,7 +34,7 @@ for n, t, c, heads, tk in ((8, 4096, 320, 8, None), (8, 1024, 640, 8, None), (8,
         t_ref = timeit(lambda: ops.attention(qkv, heads, 1, dt))
         ops.FLASH_ENABLED = True
         res = {}
-        for qt in ((1, 2) if d <= 64 else (1,)):
+        for qt in ((0, 1, 2) if d <= 64 else (0, 1)):
             _hip.lib().pmi_set_option(9, qt)
             out = ops.attention(qkv, heads, 1, dt)
             res[qt] = (timeit(lambda: ops.attention(qkv, heads, 1, dt)), float((out.float() - ref.float()).abs().max()))
@@ -47,11 +47,11 @@ for n, t, c, heads, tk in ((8, 4096, 320, 8, None), (8, 1024, 640, 8, None), (8,
         t_ref = timeit(lambda: ops.cross_attention(q, kv, heads, dt))
         ops.FLASH_ENABLED = True
         res = {}
-        for qt in ((1, 2) if d <= 64 else (1,)):
+        for qt in ((0, 1, 2) if d <= 64 else (0, 1)):
             _hip.lib().pmi_set_option(9, qt)
             out = ops.cross_attention(q, kv, heads, dt)
             res[qt] = (timeit(lambda: ops.cross_attention(q, kv, heads, dt)), float((out.float() - ref.float()).abs().max()))
         fl = 4.0 * n * heads * t * tk * d
     _hip.lib().pmi_set_option(9, 0)
     print(f"N={n} T={t} Tk={tk} C={c} heads={heads} d={d}: gemm path {t_ref:.3f} ms; " +
-          "; ".join(f"flash qt{qt} {ms:.3f} ms ({fl / ms / 1e9:.0f} TFLOP/s) maxdiff {df:.2e}" for qt, (ms, df) in res.items()), flush=True)
+          "; ".join(f"flash {'lds4' if qt == 0 else 'qt' + str(qt)} {ms:.3f} ms ({fl / ms / 1e9:.0f} TFLOP/s) maxdiff {df:.2e}" for qt, (ms, df) in res.items()), flush=True)
