@@ -315,7 +315,9 @@ def _gn_coeffs(x, x1, gamma, beta, groups, dt, film, film_ld, eps):
         call("pmi_gn_finalize", ptr(st0[0]), st0[1], c0, ptr(st1[0]) if st1 else None, st1[1] if st1 else 0, c1,
              ptr(gamma), ptr(beta), ptr(film), film_ld, ptr(ca), ptr(cb), n, hw, groups, eps)
         return ca, cb
-    nchunk = max(1, min(hw // 64, (1024 + n - 1) // n))
+    # pixel chunks per sample: ~1024 workgroups per launch, at least 8 pixels each (64 left a 16x16 map at batch 8 with 32 workgroups whose
+    # threads walked 64 pixels one dependent load after the other: 27 us per launch)
+    nchunk = max(1, min(hw // 8, (1024 + n - 1) // n))
     ws = _empty((n, nchunk, c, 2), torch.float32, dev)
     call("pmi_gn_stats", ptr(x), ptr(x1), c0, ptr(ws), n, hw, c, groups, nchunk, dt)
     call("pmi_gn_finalize", ptr(ws), nchunk, c, None, 0, 0, ptr(gamma), ptr(beta), ptr(film), film_ld, ptr(ca), ptr(cb), n, hw, groups, eps)
