@@ -167,10 +167,12 @@ int pmi_prep_input(const float* img, const float* planes, int nplanes, void* x, 
 int pmi_finish_output(const float* y, int ld, float* out, int N, int H, int W, int cout, pmi_stream_t s);
 /* StableDiffusion latents / VAE (models/stable_diffusion/stable_diffusion.py:194-198,259-271): generic NCHW fp32 <-> NHWC layout
  * conversion with an affine map (x*mul + add: the 1/0.18215 latent scale, diffusion_space.decode's (x+1)/2), and the GEGLU
- * gate of the transformer blocks' feed-forward (stable_diffusion/attention.py:346-348): h[M][2F] = (value | gate) -> value*gelu(gate). */
+ * gate of the transformer blocks' feed-forward (stable_diffusion/attention.py:346-348): h[M][2F] = (value | gate) -> value*gelu(gate);
+ * interleaved = 1: h holds 16 value then 16 gate columns per 32 (the column order of weights packed for pmi_igemm's act = 5 = GEGLU
+ * epilogue, which writes value*gelu(gate) directly -- N / 2 output columns, weights-direct GEMM only -- and makes this pass unnecessary). */
 int pmi_nchw_to_nhwc(const float* in, void* x, int N, int C, int H, int W, int Cpad, float mul, float add, int dtype, pmi_stream_t s);
 int pmi_nhwc_to_nchw(const float* y, int ld, float* out, int N, int H, int W, int cout, float mul, float add, pmi_stream_t s);
-int pmi_geglu(const void* h, void* out, int64_t M, int F, int dtype, pmi_stream_t s);
+int pmi_geglu(const void* h, void* out, int64_t M, int F, int interleaved, int dtype, pmi_stream_t s);
 int pmi_avgpool2(const void* x, void* y, int N, int H, int W, int C, int dtype, pmi_stream_t s);            /* nn.AvgPool2d(2) */
 int pmi_upsample_bilinear2(const void* x, void* y, int N, int H, int W, int C, int dtype, pmi_stream_t s);  /* align_corners=False */
 int pmi_upsample_nearest2(const void* x, void* y, int N, int H, int W, int C, pmi_stream_t s);              /* nn.Upsample(2, 'nearest'), 16-bit NHWC */

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("PMI_LIB") or os.path.join(_HERE, "csrc", "libpercepto
 
 DT_F16, DT_BF16, DT_F16X2 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_GELU, ACT_QUICKGELU = 0, 1, 2, 3, 4
+ACT_GEGLU = 5      # pmi_igemm (weights-direct GEMM only): value * gelu(gate) over (16 value | 16 gate) column groups, N / 2 output columns
 TORCH_DTYPE = {DT_F16: torch.float16, DT_BF16: torch.bfloat16, DT_F16X2: torch.float16}
 
 
@@ -82,7 +83,7 @@ _PROTOS = {
     "pmi_finish_output": ([_P, _I, _P, _I, _I, _I, _I, _P],),
     "pmi_nchw_to_nhwc": ([_P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P],),
     "pmi_nhwc_to_nchw": ([_P, _I, _P, _I, _I, _I, _I, _F, _F, _P],),
-    "pmi_geglu": ([_P, _P, _L, _I, _I, _P],),
+    "pmi_geglu": ([_P, _P, _L, _I, _I, _I, _P],),
     "pmi_avgpool2": ([_P, _P, _I, _I, _I, _I, _I, _P],),
     "pmi_upsample_bilinear2": ([_P, _P, _I, _I, _I, _I, _I, _P],),
     "pmi_upsample_nearest2": ([_P, _P, _I, _I, _I, _I, _P],),

@@ -17,6 +17,7 @@
 #define PMI_ACT_SILU 2
 #define PMI_ACT_GELU 3
 #define PMI_ACT_QUICKGELU 4
+#define PMI_ACT_GEGLU 5     /* gemm_wd only: columns are (16 value | 16 gate) per 32; output = value * gelu(gate), N / 2 columns */
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

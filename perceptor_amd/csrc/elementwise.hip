@@ -80,15 +80,17 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 
 // GEGLU (stable_diffusion/attention.py:346-348): h[M][2F] 16-bit = (value | gate) -> out[M][F] = value * gelu(gate)
 template <typename T>
-__global__ __launch_bounds__(256) void geglu_kernel(const u16* __restrict__ h, u16* __restrict__ out, int64_t M, int F) {
+__global__ __launch_bounds__(256) void geglu_kernel(const u16* __restrict__ h, u16* __restrict__ out, int64_t M, int F, int interleaved) {
   const int F8 = F >> 3;
   const int64_t total = M * F8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c8 = (int)(i % F8);
     const int64_t r = i / F8;
     float v[8], g[8];
-    unpack8<T>(*(const uint4*)(h + r * 2 * F + c8 * 8), v);
-    unpack8<T>(*(const uint4*)(h + r * 2 * F + F + c8 * 8), g);
+    // plain: (value F | gate F); interleaved: per 32 input columns 16 value then 16 gate (the layout the fused GEMM epilogue's weights use)
+    const int vo = interleaved ? (c8 >> 1) * 32 + (c8 & 1) * 8 : c8 * 8, go = interleaved ? vo + 16 : F + c8 * 8;
+    unpack8<T>(*(const uint4*)(h + r * 2 * F + vo), v);
+    unpack8<T>(*(const uint4*)(h + r * 2 * F + go), g);
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= 0.5f * g[e] * (1.f + fast_erff(g[e] * 0.70710678118654752f));
     *(uint4*)(out + r * F + c8 * 8) = pack8<T>(v);
@@ -313,11 +315,11 @@ extern "C" int pmi_nhwc_to_nchw(const float* y, int ld, float* out, int N, int H
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }
-extern "C" int pmi_geglu(const void* h, void* out, int64_t M, int F, int dtype, pmi_stream_t s) {
-  if (!h || !out || M <= 0 || F <= 0 || (F & 7) || dtype == PMI_DT_F16X2) return PMI_ERR_ARG;
+extern "C" int pmi_geglu(const void* h, void* out, int64_t M, int F, int interleaved, int dtype, pmi_stream_t s) {
+  if (!h || !out || M <= 0 || F <= 0 || (F & 7) || (interleaved && (F & 15)) || dtype == PMI_DT_F16X2) return PMI_ERR_ARG;
   dim3 grid(grid_for(M * (F / 8))), block(256);
-  if (dtype == PMI_DT_BF16) hipLaunchKernelGGL(geglu_kernel<BF16>, grid, block, 0, ST, (const u16*)h, (u16*)out, M, F);
-  else hipLaunchKernelGGL(geglu_kernel<F16>, grid, block, 0, ST, (const u16*)h, (u16*)out, M, F);
+  if (dtype == PMI_DT_BF16) hipLaunchKernelGGL(geglu_kernel<BF16>, grid, block, 0, ST, (const u16*)h, (u16*)out, M, F, interleaved);
+  else hipLaunchKernelGGL(geglu_kernel<F16>, grid, block, 0, ST, (const u16*)h, (u16*)out, M, F, interleaved);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }

@@ -136,6 +136,35 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
   GSTAMP(2);
 
   const bool raw = a.splitk > 1;
+  if (a.act == PMI_ACT_GEGLU) {
+    // ---- GEGLU epilogue (stable_diffusion/attention.py:346-348): the weights are packed so that every wave's 32 columns are 16 value
+    // columns (block 0) and their 16 gate columns (block 1): out = value * gelu(gate), 128 output columns per tile, through a 16-bit
+    // LDS image and out as 256-byte rows.  The 8C-wide projection never exists in HBM. ----
+    constexpr int GROW = 128 * 2 + 16;
+    const int cl = wid * 16 + 4 * (lane >> 4);           // output column inside the tile
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
+    if (a.bias && wave_live) { bv = *(const float4*)(a.bias + n0 + wid * 32 + 4 * (lane >> 4)); bg = *(const float4*)(a.bias + n0 + wid * 32 + 16 + 4 * (lane >> 4)); }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+      const f32x4 cv = acc[mb][0], cg = acc[mb][1];
+      float v[4] = {cv[0] * a.alpha + bv.x, cv[1] * a.alpha + bv.y, cv[2] * a.alpha + bv.z, cv[3] * a.alpha + bv.w};
+      const float g[4] = {cg[0] * a.alpha + bg.x, cg[1] * a.alpha + bg.y, cg[2] * a.alpha + bg.z, cg[3] * a.alpha + bg.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= act_apply(g[e], PMI_ACT_GELU);
+      *(uint2*)(smem + (mb * 16 + (lane & 15)) * GROW + cl * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
+    }
+    __syncthreads();
+    const int gc8 = tid & 15, grow = tid >> 4;           // 8 columns (16 B) x rows grow + 32 j
+    const int nh = a.N >> 1, nh0 = n0 >> 1;
+#pragma unroll
+    for (int j = 0; j < (TM + 31) / 32; ++j) {
+      const int r = grow + 32 * j, m = m0 + r;
+      if (r >= TM || m >= a.M || nh0 + gc8 * 8 >= nh) continue;
+      *(uint4*)((u16*)a.D + (int64_t)m * a.ldd + nh0 + gc8 * 8) = *(const uint4*)(smem + r * GROW + gc8 * 16);
+    }
+    GSTAMP(3);
+    return;
+  }
   if (!raw && !a.out_f32 && !(a.R && a.res_f32)) {
     // ---- epilogue, 16-bit output: ONE pass through a 16-bit image of the whole tile (bias + activation applied on the way in),
     // written out as 512-byte rows, 16 bytes per lane; a 16-bit residual is added on the way out ----
@@ -278,6 +307,7 @@ extern "C" int pmi_gemm_wd_eligible(const pmi_igemm_args* a) {
     if (tail < 64 || (tail < 128 && a->R && a->res_f32)) return 0;      // (N = 320 with an fp32 residual: 50 vs 45 us; without: 26 vs 29, fp32 out 34 vs 42)
   }
   if ((a->D2 || a->aux) && (a->out_f32 || a->splitk > 1 || (a->R && a->res_f32))) return 0;
+  if (a->act == PMI_ACT_GEGLU && (a->R || a->D2 || a->aux || a->out_f32 || a->splitk > 1)) return 0;
   return 1;
 }
 

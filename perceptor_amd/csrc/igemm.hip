@@ -549,6 +549,7 @@ static int g_allow_halo = 1;
 extern "C" int pmi_igemm_splitk(const pmi_igemm_args* a) {
   if (a->batch > 1 || (a->N & 3)) return 1;
   if (g_allow_halo && pmi_conv3x3_halo_config(a) >= 0) return 1;
+  if (a->act == PMI_ACT_GEGLU) return 1;
   if (pmi_gemm_wd_eligible(a)) {    // weights-direct GEMM: fill the 256 CUs with (row tile x 256-column) workgroups; >= 2 chunks of 128 per split
     const int nch = (a->K + 127) / 128;
     int best = 1;
@@ -623,6 +624,7 @@ extern "C" int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream) {
   if (a->pro_a && (!a->pro_b || halo < 0)) return PMI_ERR_ARG;
   if (a->stats && a->stats_p != pmi_igemm_stats_rows(a)) return PMI_ERR_ARG;
   if (a->splitk > 1 && (!a->ws || a->batch > 1 || halo >= 0 || (a->N & 3) || a->stats)) return PMI_ERR_ARG;
+  if (a->act == PMI_ACT_GEGLU && !pmi_gemm_wd_eligible(a)) return bad_arg(__LINE__);     // the gated epilogue exists in the weights-direct GEMM only
   if (pmi_gemm_wd_eligible(a)) {
     const int rc = pmi_gemm_wd_launch(a, stream);
     if (rc != PMI_OK || a->splitk <= 1) return rc;

@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 from .. import _hip
-from .._hip import ACT_NONE, DT_F16X2, IgemmArgs, call, ptr
+from .._hip import ACT_GEGLU, ACT_NONE, DT_F16X2, IgemmArgs, call, ptr
 
 
 HALO_ENABLED = True
@@ -178,7 +178,7 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
         assert lin.taps == 1 and not up and stride == 1
         m = a0.shape[0]
         a.hw = hw or 1
-        oshape = (m, lin.n_p)
+        oshape = (m, lin.n_p // 2 if act == ACT_GEGLU else lin.n_p)
     if lin.split:
         a.split_in = 1
         if not out_f32:                                   # precise output: hi + lo pairs, 2*N 16-bit values per row
@@ -265,6 +265,30 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
         return out
     call("pmi_igemm", C.byref(a))
     return out
+
+
+def geglu_linear(x: torch.Tensor, lin: PackedLinear) -> torch.Tensor:
+    """x [M, K] @ lin (columns packed as 16 value | 16 gate per 32: interleave_geglu) -> value * gelu(gate) [M, N / 2].
+    In the GEMM's epilogue where the weights-direct kernel takes the shape; otherwise the GEMM followed by the gate pass."""
+    dt = lin.dt
+    a = IgemmArgs()
+    a.taps, a.stride, a.M, a.N, a.K, a.C0, a.batch, a.Bf, a.act = 1, 1, x.shape[0], lin.n_p, lin.K, lin.K, 1, 1, ACT_GEGLU
+    if GEMM_WD_ENABLED and not lin.split and lin.n_p % 32 == 0 and lin.K % 32 == 0 and _hip.lib().pmi_gemm_wd_eligible(C.byref(a)):
+        return igemm(x, lin, act=ACT_GEGLU)
+    f = igemm(x, lin)
+    out = _empty((x.shape[0], lin.n_p // 2), f.dtype, f.device)
+    call("pmi_geglu", ptr(f), ptr(out), x.shape[0], lin.n_p // 2, 1, dt)
+    return out
+
+
+def interleave_geglu(weight: torch.Tensor, bias: Optional[torch.Tensor]):
+    """Rows of a GEGLU projection [2F, K] = (value F | gate F) reordered to 16 value rows, their 16 gate rows, 16 value rows, ...
+    (every 32-column slice a wave of the weights-direct GEMM owns then holds matching value / gate columns)."""
+    f = weight.shape[0] // 2
+    assert f % 16 == 0
+    idx = torch.arange(f).view(-1, 16)
+    perm = torch.cat([idx, idx + f], dim=1).flatten()
+    return weight[perm].contiguous(), (bias[perm].contiguous() if bias is not None else None)
 
 
 def fused_mlp_epilogues(lin: PackedLinear, m: int) -> bool:

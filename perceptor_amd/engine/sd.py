@@ -293,7 +293,9 @@ class SdUnetEngine(_Blocks):
                     w[b + ".q2"] = self._lin(b + ".attn2.to_q")
                     w[b + ".kv2"] = PackedLinear(cat([b + ".attn2.to_k.weight", b + ".attn2.to_v.weight"]), None, self.dt, self.device)
                     w[b + ".out2"] = self._lin(b + ".attn2.to_out.0")
-                    w[b + ".ff1"], w[b + ".ff2"] = self._lin(b + ".ff.net.0.proj"), self._lin(b + ".ff.net.2")
+                    wf, bf = ops.interleave_geglu(sd[b + ".ff.net.0.proj.weight"].detach().float(), sd[b + ".ff.net.0.proj.bias"].detach().float())
+                    w[b + ".ff1"] = PackedLinear(wf, bf, self.dt, self.device)      # (16 value | 16 gate) column groups: GEGLU in the GEMM's epilogue
+                    w[b + ".ff2"] = self._lin(b + ".ff.net.2")
                 else:
                     self.w[l[1]] = self._lin(l[1])
         self.emb_all = PackedLinear(torch.cat(emb_w, 0), torch.cat(emb_b, 0), self.dt, self.device)
@@ -334,9 +336,7 @@ class SdUnetEngine(_Blocks):
         q = ops.igemm(self._ln(h, w[b + ".norm2"], m, c), w[b + ".q2"])
         a = ops.cross_attention(q.view(n, t, c), kv_all[b + ".kv2"].view(n, tc, 2 * c), heads, dt)
         h = ops.igemm(a.view(m, c), w[b + ".out2"], residual=h, out_f32=True)
-        f = ops.igemm(self._ln(h, w[b + ".norm3"], m, c), w[b + ".ff1"])                          # [m, 8c] = (value | gate)
-        gg = torch.empty((m, 4 * c), dtype=f.dtype, device=f.device)
-        call("pmi_geglu", ptr(f), ptr(gg), m, 4 * c, dt)
+        gg = ops.geglu_linear(self._ln(h, w[b + ".norm3"], m, c), w[b + ".ff1"])                  # value * gelu(gate), [m, 4c]
         h16 = ops.igemm(gg, w[b + ".ff2"], residual=h)                                            # fp32 residual in, 16-bit tokens out
         out = ops.igemm(h16, w[k + ".proj_out"], residual=x.view(m, c), want_stats=True, hw=t)
         o4 = out.view(n, hh, ww, c)

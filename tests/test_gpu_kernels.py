@@ -198,6 +198,31 @@ def test_gemm_wd(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("m, k, f", [(4096, 320, 1280), (1000, 640, 2560), (300, 1280, 5120), (40, 320, 1280)])
+def test_geglu_linear_fused_epilogue_and_fallback(m, k, f, dtype):
+    """GEGLU feed-forward projection (stable_diffusion/attention.py:346-348): value * gelu(gate) from the weights-direct GEMM's epilogue
+    (weights packed as 16 value | 16 gate column groups); m = 40 is below the kernel's row minimum: GEMM + the interleaved gate pass."""
+    from perceptor_amd.engine import ops
+    from perceptor_amd._hip import dtype_code
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    x = _r(torch.randn(m, k, generator=g), dtype)
+    wt = _r(torch.randn(2 * f, k, generator=g) / k ** 0.5, dtype)
+    b = torch.randn(2 * f, generator=g) * 0.1
+    h = x @ wt.T + b
+    ref = h[:, :f] * F.gelu(h[:, f:])
+    wi, bi = ops.interleave_geglu(wt, b)
+    lin = ops.PackedLinear(wi, bi, dtype_code(dtype), dev)
+    td = torch.float16 if dtype == "f16" else torch.bfloat16
+    out = ops.geglu_linear(x.to(td).to(dev), lin)
+    assert out.shape == (m, f)
+    if m >= 64:
+        _check(out.cpu(), ref, dtype)
+    else:   # the projection is rounded to 16 bit before the gate pass: one more rounding than the fused epilogue
+        assert float((out.float().cpu() - ref).abs().max()) <= 4 * ULP[dtype] * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [dict(c=64, g=32, film=True, pool=False), dict(c=256, g=32, film=False, pool=True),
                                   dict(c=96, g=1, film=True, pool=False, affine=False), dict(c=384, g=32, split=256)])
 def test_group_norm(case, dtype):
