@@ -267,7 +267,7 @@ def main_sd(a, rank, world, dev, dist):
                                "kind": "port", "sample": f"one oracle UNet evaluation at batch 1, {sres}x{sres} latents = {t_eval:.2f}s, scaled x{scale:.0f} "
                                                          "(pixels x batch x 2 evaluations per CFG step)"}
         out["parity"] = {"eps_max_abs_err": float((got - want).abs().max()), "eps_max_abs": float(want.abs().max()),
-                         "sample": f"batch 1, {sres}x{sres} latents, index 600, vs the CPU fp32 oracle (parity unpinned against diffusers itself)"}
+                         "sample": f"batch 1, {sres}x{sres} latents, index 600, vs the CPU fp32 oracle (pinned on the reference's vendored CompVis UNet, tests/golden/sd_ldm_*.npz)"}
     print(json.dumps(out), flush=True)
 
 

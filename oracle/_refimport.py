@@ -4,12 +4,14 @@ Loads the reference's hot-path source files *unmodified* from /root/reference
 so golden vectors can be generated from the real code.  The
 reference package's __init__ files import heavy third-party packages that are
 not installed (lantern, basicsr, torchvision, open_clip, ...), so empty package
-shells are registered in sys.modules first and only three tiny stand-ins are
+shells are registered in sys.modules first and only four tiny stand-ins are
 provided for symbols the hot-path files touch at import time:
 
   lantern.Tensor / lantern.FunctionalBase   (type annotation + frozen record)
   basicsr.utils.download_util.load_file_from_url   (raises: no network)
   torchvision.transforms.functional          (imported, never called)
+  omegaconf.listconfig.ListConfig            (an empty class: the vendored ldm UNet only asks `type(context_dim) == ListConfig`)
+(gen_tokenizer additionally registers an identity `ftfy.fix_text` for ASCII prompts; no arithmetic of any path is replaced.)
 
 Nothing from the reference is copied into this repository; only numeric
 inputs/outputs are written to tests/golden/.
@@ -87,6 +89,15 @@ def install() -> None:
     _shell("perceptor.models.velocity_diffusion", os.path.join(p, "models", "velocity_diffusion"))
     _shell("perceptor.models.ruclip", os.path.join(p, "models", "ruclip"))
     _shell("perceptor.models.slip", os.path.join(p, "models", "slip"))      # only its tokenizer.py is loaded (gen_tokenizer)
+    # omegaconf (absent): the vendored ldm UNet only asks `type(context_dim) == ListConfig` (openaimodel.py:494-497): an empty class answers no
+    oc = _shell("omegaconf", "")
+    ocl = _shell("omegaconf.listconfig")
+    ocl.ListConfig = type("ListConfig", (), {})
+    oc.listconfig = ocl
+    # the vendored CompVis latent-diffusion code (the original StableDiffusion UNet / VAE): oracle/gen_golden.py: gen_sd_ldm
+    ld = os.path.join(p, "models", "latent_diffusion")
+    for sub in ("", ".ldm", ".ldm.modules", ".ldm.modules.diffusionmodules", ".ldm.modules.distributions", ".ldm.models"):
+        _shell("perceptor.models.latent_diffusion" + sub, os.path.join(ld, *sub.strip(".").split(".")) if sub else ld)
     _shell("perceptor.transforms", os.path.join(p, "transforms"))
     _shell("perceptor.transforms.resize", os.path.join(p, "transforms", "resize"))
     utils = _shell("perceptor.utils", os.path.join(p, "utils"))

@@ -459,6 +459,105 @@ def gen_clip_hf_model():
          distance=dist.detach(), grad=g)
 
 
+def _ldm_unet_keys(cfg, sd):
+    """diffusers key names (what the StableDiffusion engines / oracle use) -> the key names of the reference's vendored CompVis UNetModel
+    (models/latent_diffusion/ldm/modules/diffusionmodules/openaimodel.py:413-1009), for layers_per_block = 2 ... any; the published
+    checkpoint-conversion correspondence between the two layouts of the SAME network, restated."""
+    L, nl = cfg.layers_per_block, len(cfg.block_out)
+    res = (("norm1", "in_layers.0"), ("conv1", "in_layers.2"), ("time_emb_proj", "emb_layers.1"), ("norm2", "out_layers.0"),
+           ("conv2", "out_layers.3"), ("conv_shortcut", "skip_connection"))
+    pre = {"time_embedding.linear_1": "time_embed.0", "time_embedding.linear_2": "time_embed.2", "conv_in": "input_blocks.0.0",
+           "conv_norm_out": "out.0", "conv_out": "out.2", "mid_block.resnets.0": "middle_block.0", "mid_block.attentions.0": "middle_block.1",
+           "mid_block.resnets.1": "middle_block.2"}
+    for i in range(nl):
+        for j in range(L):
+            pre[f"down_blocks.{i}.resnets.{j}"] = f"input_blocks.{1 + i * (L + 1) + j}.0"
+            pre[f"down_blocks.{i}.attentions.{j}"] = f"input_blocks.{1 + i * (L + 1) + j}.1"
+        pre[f"down_blocks.{i}.downsamplers.0.conv"] = f"input_blocks.{(i + 1) * (L + 1)}.0.op"
+    ca = list(reversed(cfg.cross_attn))
+    for i in range(nl):
+        for j in range(L + 1):
+            pre[f"up_blocks.{i}.resnets.{j}"] = f"output_blocks.{i * (L + 1) + j}.0"
+            pre[f"up_blocks.{i}.attentions.{j}"] = f"output_blocks.{i * (L + 1) + j}.1"
+        pre[f"up_blocks.{i}.upsamplers.0.conv"] = f"output_blocks.{i * (L + 1) + L}.{2 if ca[i] else 1}.conv"
+    out = {}
+    for k, v in sd.items():
+        hit = max((p for p in pre if k.startswith(p + ".")), key=len)
+        rest = k[len(hit) + 1:]
+        if ".resnets." in hit or hit in ("mid_block.resnets.0", "mid_block.resnets.1"):
+            for a, b in res:
+                if rest.startswith(a + "."):
+                    rest = b + rest[len(a):]
+                    break
+        out[pre[hit] + "." + rest] = v
+    return out
+
+
+def _ldm_vae_keys(cfg, sd, part):
+    """diffusers AutoencoderKL key names -> the reference's vendored ldm Encoder / Decoder (ldm/modules/diffusionmodules/model.py:379-600)."""
+    nl, out = len(cfg.block_out), {}
+    res = (("conv_shortcut", "nin_shortcut"),)
+    att = (("group_norm", "norm"), ("query", "q"), ("key", "k"), ("value", "v"), ("proj_attn", "proj_out"))
+    for k, v in sd.items():
+        if not k.startswith(part + "."):
+            continue
+        r = k[len(part) + 1:]
+        r = r.replace("mid_block.resnets.0", "mid.block_1").replace("mid_block.resnets.1", "mid.block_2").replace("mid_block.attentions.0", "mid.attn_1")
+        r = r.replace("conv_norm_out", "norm_out")
+        for i in range(nl):
+            for j in range(cfg.layers_per_block + 1):
+                r = r.replace(f"up_blocks.{i}.resnets.{j}.", f"up.{nl - 1 - i}.block.{j}.").replace(f"down_blocks.{i}.resnets.{j}.", f"down.{i}.block.{j}.")
+            r = r.replace(f"up_blocks.{i}.upsamplers.0.", f"up.{nl - 1 - i}.upsample.").replace(f"down_blocks.{i}.downsamplers.0.", f"down.{i}.downsample.")
+        for a, b in res:
+            r = r.replace(a, b)
+        if "attn_1" in r:
+            for a, b in att:
+                r = r.replace("." + a + ".", "." + b + ".")
+            if r.endswith(".weight") and v.ndim == 2:
+                v = v[:, :, None, None]          # linear -> the 1x1 convolution the ldm AttnBlock holds
+        out[r] = v
+    return out
+
+
+def gen_sd_ldm():
+    """StableDiffusion's UNet and VAE as the REFERENCE's own tree holds them: the vendored CompVis latent-diffusion modules
+    (models/latent_diffusion/ldm/...: openaimodel.UNetModel with SpatialTransformer = the original of diffusers' UNet2DConditionModel;
+    model.Encoder / Decoder = the halves of AutoencoderKL).  diffusers 0.6.0 itself is absent; these are the same published network under the
+    original key layout, so they pin oracle/sd.py's restatement with reference code: tiny UNet in full, the 860 M SD-v1 UNet at 16x16 latents
+    with a 77-token context, tiny and SD-v1 VAE decoder / encoder."""
+    from oracle import sd as osd
+    from perceptor_amd.utils.synth import synth_state_dict
+    om = R.ref("models.latent_diffusion.ldm.modules.diffusionmodules.openaimodel")
+    mm = R.ref("models.latent_diffusion.ldm.modules.diffusionmodules.model")
+    for tag, cfg, n, hw, tc in (("tiny", osd.SD_TINY, 2, 16, 7), ("v1", osd.SD_V1, 1, 16, 77)):
+        bo = cfg.block_out
+        ds_attn = [2 ** i for i, c in enumerate(cfg.cross_attn) if c]
+        m = om.UNetModel(image_size=hw, in_channels=cfg.in_channels, out_channels=cfg.out_channels, model_channels=bo[0], attention_resolutions=ds_attn,
+                         num_res_blocks=cfg.layers_per_block, channel_mult=[c // bo[0] for c in bo], num_heads=cfg.heads, use_spatial_transformer=True,
+                         transformer_depth=1, context_dim=cfg.context_dim, use_checkpoint=False, legacy=False).eval()
+        sd = synth_state_dict(osd.unet_state_dict_shapes(cfg), 0)
+        m.load_state_dict(_ldm_unet_keys(cfg, sd), strict=True)
+        x, ctx = seeded_noise((n, cfg.in_channels, hw, hw), 71), seeded_noise((n, tc, cfg.context_dim), 72)
+        t = torch.tensor([981, 20][:n])
+        with torch.no_grad():
+            y = m(x, t, context=ctx)
+        save(f"sd_ldm_unet_{tag}", eps=y, t=t, hw=np.array(hw), tc=np.array(tc))
+    for tag, cfg, hw in (("tiny", osd.VAE_TINY, 16), ("v1", osd.VAE_V1, 8)):
+        dd = dict(ch=cfg.block_out[0], out_ch=cfg.out_channels, ch_mult=tuple(c // cfg.block_out[0] for c in cfg.block_out), num_res_blocks=cfg.layers_per_block,
+                  attn_resolutions=[], in_channels=cfg.out_channels, resolution=256, z_channels=cfg.latent_channels)
+        sd = synth_state_dict({**osd.vae_encoder_state_dict_shapes(cfg), **osd.vae_decoder_state_dict_shapes(cfg)}, 0)
+        dec, enc = mm.Decoder(**dd).eval(), mm.Encoder(**dd, double_z=True).eval()
+        dec.load_state_dict(_ldm_vae_keys(cfg, sd, "decoder"), strict=True)
+        enc.load_state_dict(_ldm_vae_keys(cfg, sd, "encoder"), strict=True)
+        z = seeded_noise((1, cfg.latent_channels, hw, hw), 73)
+        img = seeded_noise((1, 3, 8 * hw if tag == "v1" else 2 * hw, 8 * hw if tag == "v1" else 2 * hw), 74) * 0.5
+        with torch.no_grad():
+            # post_quant_conv / quant_conv are 1x1 convolutions of AutoencoderKL itself (ldm/models/autoencoder.py needs pytorch_lightning): plain conv2d here
+            y = dec(torch.nn.functional.conv2d(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"]))
+            mom = torch.nn.functional.conv2d(enc(img), sd["quant_conv.weight"], sd["quant_conv.bias"])
+        save(f"sd_ldm_vae_{tag}", dec=y, mean=mom[:, :cfg.latent_channels], logvar=mom[:, cfg.latent_channels:], hw=np.array(hw), img_hw=np.array(img.shape[-1]))
+
+
 TOKENIZER_PROMPTS = [
     "a photograph of a playful cat", "painting of a dog", "", "  Hello,   World!  it's 2023 -- don't panic...",
     "An astronaut riding a horse on Mars; 4k, trending on artstation (highly detailed)", "fish &amp; chips &lt;3 #tasty @home 100% / 50$",

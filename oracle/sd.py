@@ -2,10 +2,14 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file; the product path never does.
 
-PARITY UNPINNED.  The UNet and VAE arithmetic lives in diffusers 0.6.0 (poetry.lock:365-366; `UNet2DConditionModel`,
-`AutoencoderKL`, `DDPMScheduler` used at perceptor/models/stable_diffusion/stable_diffusion.py:82-100,259-271), which is not
-vendored and not installed here, and the reference's only value test for it (`test_stable_diffusion_step`, :574-658) needs
-downloaded weights.  What IS in the reference tree is restated from there:
+PINNING.  The UNet and VAE arithmetic of the reference's StableDiffusion path lives in diffusers 0.6.0 (poetry.lock:365-366;
+`UNet2DConditionModel`, `AutoencoderKL`, `DDPMScheduler` used at perceptor/models/stable_diffusion/stable_diffusion.py:82-100,259-271), which is
+not vendored and not installed here, and the reference's only value test for it (`test_stable_diffusion_step`, :574-658) needs downloaded
+weights: parity with diffusers' OWN code is unpinned.  The network itself is pinned with reference code: the reference vendors the CompVis
+latent-diffusion modules the diffusers classes are ports of (perceptor/models/latent_diffusion/ldm/modules/diffusionmodules/openaimodel.py:
+UNetModel with SpatialTransformer; .../model.py: Encoder / Decoder of AutoencoderKL), and tests/golden/sd_ldm_*.npz hold THEIR outputs on the
+name-keyed weights under the published diffusers <-> CompVis key correspondence (oracle/gen_golden.py: gen_sd_ldm, strict loads): this file
+matches them to 3e-5 on the full 860 M-parameter SD-v1 UNet and on both VAE halves (tests/test_oracle_golden.py).  Also restated from the tree:
   stable_diffusion/attention.py:120-188   SpatialTransformer (GroupNorm eps 1e-6, 1x1 in/out, residual)
   stable_diffusion/attention.py:191-247   BasicTransformerBlock (attn1 self, attn2 cross, GEGLU feed-forward, pre-LayerNorm, residuals)
   stable_diffusion/attention.py:250-298   CrossAttention (to_q/to_k/to_v without bias, softmax(q k^T d^-1/2) v = the xformers call at :285, to_out)
@@ -13,7 +17,7 @@ downloaded weights.  What IS in the reference tree is restated from there:
   stable_diffusion/attention.py:23-117    AttentionBlock (VAE mid block: q/k/v linears, both scaled by d^-1/4, fp32 softmax, proj_attn, residual)
   stable_diffusion/predictions.py:51-98,243-250   denoised_latents, DDIM step, classifier_free_guidance
   stable_diffusion/stable_diffusion.py:98-114     scaled-linear beta schedule 0.00085..0.012 -> sqrt(alpha-bar), sqrt(1 - alpha-bar)
-The rest restates the published diffusers 0.6.0 algorithm (UNet2DConditionModel.forward: sinusoidal timesteps [cos|sin] with
+The layer wiring restates the published diffusers 0.6.0 algorithm (UNet2DConditionModel.forward: sinusoidal timesteps [cos|sin] with
 flip_sin_to_cos, two-layer time MLP, ResnetBlock2D with additive time projection, CrossAttnDown/Up blocks, stride-2 conv
 down-sampling with padding 1, nearest x2 + conv up-sampling, skip concat [h, skip]; AutoencoderKL.decode: post_quant_conv, mid block,
 four up blocks of three ResnetBlock2D (eps 1e-6), GroupNorm+SiLU+conv out) over the diffusers state-dict key names.

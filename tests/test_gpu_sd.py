@@ -1,8 +1,8 @@
 """GPU parity of the StableDiffusion engines (engine/sd.py) against the CPU fp32 oracle (oracle/sd.py) on identical name-keyed weights.
 
-PARITY UNPINNED against diffusers 0.6.0 itself (absent here; see oracle/sd.py): these tests pin the HIP path to the restatement, the
-restatement's parameter inventory to the published SD-v1 figures (686 tensors / 859 520 964 parameters for the UNet, checked in
-tests/test_host_logic.py), and its transformer blocks to the reference's in-tree attention.py by reading.
+The oracle is pinned on the reference's vendored CompVis latent-diffusion UNet / VAE (tests/golden/sd_ldm_*.npz, tests/test_oracle_golden.py;
+diffusers 0.6.0's own code is absent here, see oracle/sd.py), and test_sd_v1_and_vae_vs_reference_ldm_goldens below compares the HIP engines
+with those reference outputs directly; the parameter inventory equals the published SD-v1 figures (tests/test_host_logic.py).
 Tolerances (max-abs relative to max|output|, rel-L2): f16 <= 6e-3 / 4e-3, bf16 <= 4e-2 / 2.5e-2 (same budget as the ADM UNet's 16-bit modes).
 """
 import pytest
@@ -177,3 +177,36 @@ def test_sample_loop_schedule_and_errors():
         models.StableDiffusion("runwayml/stable-diffusion-inpainting")
     with pytest.raises(RuntimeError):
         models.StableDiffusion(weights="pretrained")
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_sd_v1_and_vae_vs_reference_ldm_goldens(dtype):
+    """HIP engines against outputs of the REFERENCE's vendored CompVis UNetModel / Encoder / Decoder (oracle/gen_golden.py: gen_sd_ldm):
+    tiny UNet, the full 860 M SD-v1 UNet at 16x16 latents with a 77-token context, tiny and SD-v1 VAE."""
+    import numpy as np
+    from conftest import golden
+    from oracle import sd as osd
+    from perceptor_amd.engine import sd
+    from perceptor_amd.utils.synth import seeded_noise, synth_state_dict
+    for tag, ocfg in (("tiny", osd.SD_TINY), ("v1", osd.SD_V1)):
+        g = golden(f"sd_ldm_unet_{tag}")
+        cfg = sd.SdConfig(**ocfg.__dict__)
+        n, hw, tc = g["eps"].shape[0], int(g["hw"]), int(g["tc"])
+        eng = sd.SdUnetEngine(cfg, synth_state_dict(sd.unet_state_dict_shapes(cfg), 0), "cuda", dtype)
+        x, ctx = seeded_noise((n, cfg.in_channels, hw, hw), 71), seeded_noise((n, tc, cfg.context_dim), 72)
+        emax, el2 = _err(eng.forward(x.cuda(), g["t"].cuda(), ctx.cuda()).cpu(), g["eps"])
+        assert emax < TOL[dtype][0] and el2 < TOL[dtype][1], (tag, emax, el2)
+        del eng
+    for tag, ocfg in (("tiny", osd.VAE_TINY), ("v1", osd.VAE_V1)):
+        g = golden(f"sd_ldm_vae_{tag}")
+        cfg = sd.VaeConfig(**ocfg.__dict__)
+        w = synth_state_dict({**sd.vae_encoder_state_dict_shapes(cfg), **sd.vae_decoder_state_dict_shapes(cfg)}, 0)
+        hw, ihw = int(g["hw"]), int(g["img_hw"])
+        dec = sd.VaeDecoderEngine(cfg, w, "cuda", dtype).forward(seeded_noise((1, cfg.latent_channels, hw, hw), 73).cuda(), scale=1.0, to_images=False).cpu()
+        emax, el2 = _err(dec, g["dec"])
+        assert emax < TOL[dtype][0] and el2 < TOL[dtype][1], (tag, "dec", emax, el2)
+        img = seeded_noise((1, 3, ihw, ihw), 74) * 0.5                       # the decoder-space x in [-1, 1]; the engine takes images in [0, 1]
+        mean, logvar = sd.VaeEncoderEngine(cfg, w, "cuda", dtype).forward(((img + 1) / 2).cuda())
+        emax, el2 = _err(mean.cpu(), g["mean"])
+        assert emax < TOL[dtype][0] and el2 < TOL[dtype][1], (tag, "mean", emax, el2)
+        assert _err(logvar.cpu(), g["logvar"])[1] < TOL[dtype][1]

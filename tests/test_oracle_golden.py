@@ -245,3 +245,37 @@ def test_transformers_key_mapping_against_clipmodel_fixture():
     assert float((ie - g["image_embeds"]).abs().max()) < 2e-5 * (1 + float(g["image_embeds"].abs().max()))
     assert float((te - g["text_embeds"]).abs().max()) < 2e-5 * (1 + float(g["text_embeds"].abs().max()))
     assert float((hidden - g["text_hidden"]).abs().max()) < 2e-5 * (1 + float(g["text_hidden"].abs().max()))
+
+
+@pytest.mark.parametrize("tag", ["tiny", "v1"])
+def test_sd_unet_vs_reference_ldm(tag):
+    """oracle/sd.py's UNet restatement against the REFERENCE's vendored CompVis UNetModel (the original of diffusers' UNet2DConditionModel,
+    perceptor/models/latent_diffusion/ldm/modules/diffusionmodules/openaimodel.py) on the same name-keyed weights under the published key
+    correspondence (oracle/gen_golden.py: gen_sd_ldm): tiny config in full, the 860 M-parameter SD-v1 configuration at 16x16 latents."""
+    from oracle import sd as osd
+    from perceptor_amd.utils.synth import seeded_noise
+    g = golden(f"sd_ldm_unet_{tag}")
+    cfg = osd.SD_TINY if tag == "tiny" else osd.SD_V1
+    n, hw, tc = g["eps"].shape[0], int(g["hw"]), int(g["tc"])
+    w = synth_state_dict(osd.unet_state_dict_shapes(cfg), 0)
+    x, ctx = seeded_noise((n, cfg.in_channels, hw, hw), 71), seeded_noise((n, tc, cfg.context_dim), 72)
+    with torch.no_grad():
+        eps = osd.unet_forward(w, cfg, x, g["t"], ctx)
+    assert float((eps - g["eps"]).abs().max()) < 3e-5 * (1 + float(g["eps"].abs().max()))
+
+
+@pytest.mark.parametrize("tag", ["tiny", "v1"])
+def test_sd_vae_vs_reference_ldm(tag):
+    """VAE decoder and encoder of oracle/sd.py against the reference's vendored ldm Decoder / Encoder (ldm/modules/diffusionmodules/model.py)."""
+    from oracle import sd as osd
+    from perceptor_amd.utils.synth import seeded_noise
+    g = golden(f"sd_ldm_vae_{tag}")
+    cfg = osd.VAE_TINY if tag == "tiny" else osd.VAE_V1
+    hw, ihw = int(g["hw"]), int(g["img_hw"])
+    w = synth_state_dict({**osd.vae_encoder_state_dict_shapes(cfg), **osd.vae_decoder_state_dict_shapes(cfg)}, 0)
+    with torch.no_grad():
+        dec = osd.vae_decode(w, cfg, seeded_noise((1, cfg.latent_channels, hw, hw), 73))
+        mean, logvar = osd.vae_encode_moments(w, cfg, seeded_noise((1, 3, ihw, ihw), 74) * 0.5)
+    assert float((dec - g["dec"]).abs().max()) < 3e-5 * (1 + float(g["dec"].abs().max()))
+    assert float((mean - g["mean"]).abs().max()) < 3e-5 * (1 + float(g["mean"].abs().max()))
+    assert float((logvar - g["logvar"]).abs().max()) < 3e-5 * (1 + float(g["logvar"].abs().max()))
