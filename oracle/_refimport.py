@@ -88,6 +88,7 @@ def install() -> None:
     _shell("perceptor.models.guided_diffusion", os.path.join(p, "models", "guided_diffusion"))
     _shell("perceptor.models.velocity_diffusion", os.path.join(p, "models", "velocity_diffusion"))
     _shell("perceptor.models.ruclip", os.path.join(p, "models", "ruclip"))
+    _shell("perceptor.models.stable_diffusion", os.path.join(p, "models", "stable_diffusion"))   # predictions.py / conditioning.py / diffusion_space.py only
     _shell("perceptor.models.slip", os.path.join(p, "models", "slip"))      # only its tokenizer.py is loaded (gen_tokenizer)
     # omegaconf (absent): the vendored ldm UNet only asks `type(context_dim) == ListConfig` (openaimodel.py:494-497): an empty class answers no
     oc = _shell("omegaconf", "")

@@ -459,6 +459,41 @@ def gen_clip_hf_model():
          distance=dist.detach(), grad=g)
 
 
+def gen_sd_predictions():
+    """The latent eps-form Predictions of the reference's StableDiffusion path (models/stable_diffusion/predictions.py:10-250), run as the
+    reference class: DDIM (eta = 0 and > 0 with injected noise), reverse / noisy-reverse / resample steps, guidance, classifier-free
+    guidance, forced variants, latent thresholding, Wasserstein statistics; encode / decode are identity callables here (the VAE is pinned
+    separately).  The schedule is DDPMScheduler's scaled-linear table, restated (diffusers is absent): fp32 linspace of sqrt(beta)."""
+    P = R.ref("models.stable_diffusion.predictions").Predictions
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+    ac = torch.cumprod(1.0 - betas, dim=0)
+    alphas, sigmas = ac.sqrt(), (1 - ac).sqrt()
+    x = seeded_noise((2, 4, 16, 16), 31)
+    eps, eps2, noise, guide = (seeded_noise((2, 4, 16, 16), s_) for s_ in (32, 33, 34, 35))
+    fi, ti, hi = torch.tensor([900, 37]), torch.tensor([850, 0]), torch.tensor([950, 400])
+    ident = lambda t: t
+    LT = sys.modules["lantern"].Tensor        # these two fields are annotated with the bare lantern.Tensor type: present the tables as that (sub)type
+    mk = lambda e: P(from_diffused_latents=x, from_indices=fi, predicted_noise=e, schedule_alphas=alphas.as_subclass(LT),
+                     schedule_sigmas=sigmas.as_subclass(LT), encode=ident, decode=ident)
+    real = torch.randn_like
+    torch.randn_like = lambda t, **kw: noise.to(t)
+    try:
+        p, p2 = mk(eps), mk(eps2)
+        out = dict(x=x, eps=eps, eps2=eps2, noise=noise, guide=guide * 1e-6, fi=fi, ti=ti, hi=hi,
+                   denoised=p.denoised_latents, step=p.step(ti), step_eta=p.step(ti, eta=0.7), reverse=p.reverse_step(hi),
+                   resample_noise=p.resample_noise(ti), resample=p.resample(ti), noisy_reverse=p.noisy_reverse_step(hi),
+                   guided=p.guided(guide * 1e-6, guidance_scale=0.5, clamp_value=1e-6).predicted_noise,
+                   cfg=p.classifier_free_guidance(p2, guidance_scale=7.0).predicted_noise,
+                   forced=p.forced_denoised_latents(x * 0.5).predicted_noise,
+                   # (the [N] threshold only broadcasts for N = 1 upstream, as in the guided-diffusion class: one sample)
+                   latent_thr=P(from_diffused_latents=x[:1], from_indices=fi[:1], predicted_noise=eps[:1] * 3, schedule_alphas=alphas.as_subclass(LT),
+                                schedule_sigmas=sigmas.as_subclass(LT), encode=ident, decode=ident).latent_dynamic_threshold(0.95).predicted_noise,
+                   wasserstein=torch.stack([p.wasserstein_distance(), p.wasserstein_square_distance()]))
+    finally:
+        torch.randn_like = real
+    save("sd_predictions", **out)
+
+
 def _ldm_unet_keys(cfg, sd):
     """diffusers key names (what the StableDiffusion engines / oracle use) -> the key names of the reference's vendored CompVis UNetModel
     (models/latent_diffusion/ldm/modules/diffusionmodules/openaimodel.py:413-1009), for layers_per_block = 2 ... any; the published

@@ -210,3 +210,33 @@ def test_sd_v1_and_vae_vs_reference_ldm_goldens(dtype):
         emax, el2 = _err(mean.cpu(), g["mean"])
         assert emax < TOL[dtype][0] and el2 < TOL[dtype][1], (tag, "mean", emax, el2)
         assert _err(logvar.cpu(), g["logvar"])[1] < TOL[dtype][1]
+
+
+def test_sd_predictions_class_vs_reference_class_golden():
+    """models.stable_diffusion.Predictions against the REFERENCE class (models/stable_diffusion/predictions.py) on the same inputs
+    (oracle/gen_golden.py: gen_sd_predictions; noise injected where the reference draws it)."""
+    from conftest import golden
+    from perceptor_amd.engine import sampler
+    from perceptor_amd.models.stable_diffusion import Predictions
+    from oracle import sd as osd
+    g = golden("sd_predictions")
+    a, s = (t.cuda() for t in osd.schedule())
+    ident = lambda t: t
+    mk = lambda e, sl=slice(None): Predictions(from_diffused_latents=g["x"][sl].cuda(), from_indices=g["fi"][sl].cuda(), predicted_noise=e[sl].cuda(),
+                                                schedule_alphas=a, schedule_sigmas=s, encode=ident, decode=ident)
+    p, p2 = mk(g["eps"]), mk(g["eps2"])
+    close = lambda got, key, tol=3e-6: float((got.cpu() - g[key]).abs().max()) <= tol * (1 + float(g[key].abs().max()))
+    real = sampler.randn_like
+    sampler.randn_like = lambda t: g["noise"].to(t)
+    try:
+        assert close(p.denoised_latents, "denoised") and close(p.step(g["ti"]), "step") and close(p.step(g["ti"], eta=0.7), "step_eta")
+        assert close(p.reverse_step(g["hi"]), "reverse") and close(p.resample_noise(g["ti"]), "resample_noise") and close(p.resample(g["ti"]), "resample")
+        assert close(p.noisy_reverse_step(g["hi"]), "noisy_reverse")
+    finally:
+        sampler.randn_like = real
+    assert close(p.guided(g["guide"].cuda(), guidance_scale=0.5, clamp_value=1e-6).predicted_noise, "guided")
+    assert close(p.classifier_free_guidance(p2, guidance_scale=7.0).predicted_noise, "cfg", 1e-5)
+    assert close(p.forced_denoised_latents(g["x"].cuda() * 0.5).predicted_noise, "forced", 1e-5)
+    assert close(mk(g["eps"] * 3, slice(0, 1)).latent_dynamic_threshold(0.95).predicted_noise, "latent_thr")
+    w = torch.stack([p.wasserstein_distance(), p.wasserstein_square_distance()])
+    assert float((w.cpu() - g["wasserstein"]).abs().max()) <= 2e-6
