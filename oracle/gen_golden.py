@@ -459,6 +459,21 @@ def gen_clip_hf_model():
          distance=dist.detach(), grad=g)
 
 
+def gen_sd_schedule():
+    """StableDiffusion.schedule_indices (models/stable_diffusion/stable_diffusion.py:132-173, default rho = 3) cannot be run as that class
+    (the module imports diffusers), but its body is statement for statement GuidedDiffusion.schedule_indices (guided_diffusion.py:58-96)
+    over `self.schedule_alphas / schedule_sigmas`: the reference's GuidedDiffusion method is run here on the SD scaled-linear tables."""
+    gd = R.ref("models.guided_diffusion.guided_diffusion")
+    g = gd.GuidedDiffusion.__new__(gd.GuidedDiffusion)
+    torch.nn.Module.__init__(g)
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+    ac = torch.cumprod(1.0 - betas, dim=0)
+    g.schedule_alphas = torch.nn.Parameter(ac.sqrt(), requires_grad=False)
+    g.schedule_sigmas = torch.nn.Parameter((1 - ac).sqrt(), requires_grad=False)
+    save("sd_schedule", idx_50=g.schedule_indices(n_steps=50, rho=3.0), idx_500=g.schedule_indices(n_steps=500, rho=3.0),
+         idx_20_500_20=g.schedule_indices(n_steps=20, from_index=500, to_index=20, rho=3.0))
+
+
 def gen_sd_predictions():
     """The latent eps-form Predictions of the reference's StableDiffusion path (models/stable_diffusion/predictions.py:10-250), run as the
     reference class: DDIM (eta = 0 and > 0 with injected noise), reverse / noisy-reverse / resample steps, guidance, classifier-free

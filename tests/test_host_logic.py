@@ -205,3 +205,15 @@ def test_sd_parameter_inventory_matches_published_figures():
     a, s = osd.schedule()
     assert a.shape == (1000,) and abs(float(a[0]) ** 2 - (1 - 0.00085)) < 1e-6 and abs(float(a[-1]) ** 2 - 0.0046602) < 1e-5
     assert torch.allclose(a ** 2 + s ** 2, torch.ones(1000), atol=1e-6)
+
+
+def test_sd_schedule_indices_match_reference_method_on_sd_tables():
+    """StableDiffusion.schedule_indices against the reference's schedule_indices body run on the scaled-linear tables (gen_sd_schedule)."""
+    from perceptor_amd import models
+    g = golden("sd_schedule")
+    from perceptor_amd.engine import sd
+    m = models.StableDiffusion(config=sd.SdConfig(block_out=(32, 64), cross_attn=(True, False), heads=2, context_dim=32, layers_per_block=1),
+                               vae_config=sd.VaeConfig(block_out=(32, 64), layers_per_block=1), text_config=(16, 96, 32, 1, 1, 32))
+    assert torch.equal(m.schedule_indices(n_steps=50).cpu(), g["idx_50"])
+    assert torch.equal(m.schedule_indices().cpu(), g["idx_500"])
+    assert torch.equal(m.schedule_indices(n_steps=20, from_index=500, to_index=20).cpu(), g["idx_20_500_20"])
