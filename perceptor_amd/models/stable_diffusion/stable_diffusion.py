@@ -11,7 +11,8 @@ Deliberate, visible differences:
   * compute needs a HIP device; CPU calls raise RuntimeError;
   * ``sample`` evaluates the unconditioned and the conditioned prediction of a step in ONE batched UNet launch sequence (batch 2N)
     instead of two calls -- same values, half the launches;
-  * the inpainting checkpoint (9 input channels, kornia blur of the masks) is not built: NotImplementedError.
+  * ``latent_masks`` restates kornia's ``gaussian_blur2d`` (reflect border, normalised 1-D Gaussian of ``int(2 * blur) + 1`` taps, applied
+    separably) -- kornia is absent here: that one helper is parity-unpinned; it runs once per conditioning on a 1-channel mask.
 """
 from __future__ import annotations
 
@@ -57,12 +58,11 @@ class StableDiffusion(torch.nn.Module):
         """
         super().__init__()
         self.name, self.decoder_name = name, decoder_name
-        if name == "runwayml/stable-diffusion-inpainting":
-            raise NotImplementedError("the inpainting checkpoint (9-channel UNet input, blurred latent masks) is not built on the HIP path")
         if weights != "synthetic" and unet_checkpoint is None:
             raise RuntimeError(f"pretrained weights {name} cannot be downloaded (no network): pass unet_checkpoint= / vae_checkpoint= "
                                "or weights='synthetic'")
-        self.config = config or sd_engine.SD_V1
+        # the inpainting checkpoint takes latents | mask | masked-image latents: 9 input channels (conditioning.py:31-40)
+        self.config = config or (sd_engine.SD_INPAINTING if name == "runwayml/stable-diffusion-inpainting" else sd_engine.SD_V1)
         self.vae_config = vae_config or sd_engine.VAE_V1
         self.text_config = tuple(text_config) if text_config is not None else TEXT_CFG
         self.compute_dtype, self.vae_dtype = ("f16" if fp16 else "bf16"), vae_dtype
@@ -228,7 +228,7 @@ class StableDiffusion(torch.nn.Module):
         if self.__dict__.get("_pair_key") != key:          # one context tensor per (prompt pair, batch): keeps the engine's k|v cache valid
             self.__dict__["_pair_key"], self.__dict__["_pair_ctx"] = key, torch.cat([ex(neutral), ex(positive)], dim=0).contiguous()
         x = diffused_latents.to(self.device)
-        eps = self._engine("unet").forward(torch.cat([x, x], dim=0), torch.cat([idx, idx], dim=0), self._pair_ctx)
+        eps = self._engine("unet").forward(torch.cat([neutral.input(x), positive.input(x)], dim=0), torch.cat([idx, idx], dim=0), self._pair_ctx)
         mk = lambda e: Predictions(from_diffused_latents=diffused_latents, from_indices=idx, predicted_noise=e.contiguous(),
                                    schedule_alphas=self.schedule_alphas, schedule_sigmas=self.schedule_sigmas, encode=self.encode, decode=self.decode)
         return mk(eps[:n]), mk(eps[n:])
@@ -248,10 +248,40 @@ class StableDiffusion(torch.nn.Module):
     def text_encodings(self, texts):
         return self.token_encodings(self.tokenize(texts))
 
+    def latent_masks(self, masks, blur):
+        """Masks [N, 1, H, W] in [0, 1] -> Gaussian-blurred, bilinearly down-sampled latent masks [N, 1, H/8, W/8] (stable_diffusion.py:325-341)."""
+        n, c, h, w = masks.shape
+        if h % 8 != 0:
+            raise ValueError("Height must be divisible by 8")
+        if w % 8 != 0:
+            raise ValueError("Width must be divisible by 8")
+        if c != 1:
+            raise ValueError("Masks must be 1-channel")
+        if masks.gt(1).any() or masks.lt(0).any():
+            raise ValueError("Masks must be between 0 and 1")
+        masks = masks.to(self.device).float()
+        if blur is not None and blur > 0:
+            ks = int(blur * 2) + 1
+            x = torch.arange(ks, device=masks.device, dtype=torch.float32) - ks // 2
+            if ks % 2 == 0:
+                x = x + 0.5
+            g = torch.exp(-x**2 / (2.0 * float(blur) ** 2))
+            g = g / g.sum()
+            p = ks // 2
+            masks = torch.nn.functional.pad(masks, (p, p, p, p), mode="reflect")
+            masks = torch.nn.functional.conv2d(torch.nn.functional.conv2d(masks, g.view(1, 1, 1, ks)), g.view(1, 1, ks, 1))
+        return torch.nn.functional.interpolate(masks, size=(h // 8, w // 8), mode="bilinear")
+
     def conditioning(self, texts: List[str] = [""], inpainting_masks=None, inpainting_images=None, mask_blur=4.0, *,
                      token_ids: Optional[torch.Tensor] = None) -> Conditioning:
-        """Conditioning from a list of texts (unconditional = the empty string), or from ``token_ids`` [N, T] directly."""
+        """Conditioning from a list of texts (unconditional = the empty string), or from ``token_ids`` [N, T] directly; with the inpainting
+        checkpoint also the latent masks and the latents of the masked images (stable_diffusion.py:343-375)."""
         enc = self.token_encodings(token_ids) if token_ids is not None else self.text_encodings(texts)
+        if self.name == "runwayml/stable-diffusion-inpainting":
+            inpainting_masks, inpainting_images = inpainting_masks.to(self.device), inpainting_images.to(self.device)
+            latent_masks = self.latent_masks(inpainting_masks, mask_blur)
+            latents = self.latents(inpainting_images * inpainting_masks.le(0.5) + 0.5 * inpainting_masks.gt(0.5).float())
+            return Conditioning(model_name=self.name, encodings=enc, inpainting_latent_masks=latent_masks, inpainting_latents=latents)
         return Conditioning(model_name=self.name, encodings=enc)
 
     def diffuse_latents(self, denoised_latents, indices, noise=None):
@@ -264,9 +294,8 @@ class StableDiffusion(torch.nn.Module):
     def sample(self, text: str, from_index: int = 999, to_index: int = 0, n_steps: int = 50, guidance_scale: float = 7.0,
                n_resample: int = 0, init_image=None, inpainting_mask=None, mask_blur: float = 4.0, replace_diffused: bool = True):
         """Helper to sample a single image (stable_diffusion.py:384-491): yields the conditioned Predictions of every step."""
-        if inpainting_mask is not None:
-            raise NotImplementedError("inpainting is not built on the HIP path")
-        neutral, positive = self.conditioning(texts=[""]), self.conditioning(texts=[text])
+        neutral = self.conditioning(texts=[""], inpainting_masks=inpainting_mask, inpainting_images=init_image, mask_blur=mask_blur)
+        positive = self.conditioning(texts=[text], inpainting_masks=inpainting_mask, inpainting_images=init_image, mask_blur=mask_blur)
         schedule_indices = self.schedule_indices(from_index=from_index, to_index=to_index, n_steps=n_steps)
         from_index = schedule_indices[0, 0]
         if init_image is None:
@@ -274,12 +303,16 @@ class StableDiffusion(torch.nn.Module):
                 raise ValueError("init_image must be provided if from_index < 999")
             diffused_latents = self.random_diffused_latents((1, 3, 512, 512))
         else:
-            diffused_latents = self.diffuse_latents(self.latents(init_image), from_index)
+            init_latents = self.latents(init_image)
+            diffused_latents = self.diffuse_latents(init_latents, from_index)
         for from_index, to_index in schedule_indices:
             for _ in range(n_resample):
                 un, pos = self.predictions_pair(diffused_latents, from_index, neutral, positive)
                 diffused_latents = un.classifier_free_guidance(pos, guidance_scale=guidance_scale).resample(to_index)
             un, pos = self.predictions_pair(diffused_latents, from_index, neutral, positive)
             diffused_latents = un.classifier_free_guidance(pos, guidance_scale=guidance_scale).step(to_index)
+            if replace_diffused and inpainting_mask is not None:     # peeks into the original masked image (stable_diffusion.py:477-483)
+                lm = positive.inpainting_latent_masks
+                diffused_latents = self.diffuse_latents(init_latents, to_index) * (1 - lm) + diffused_latents * lm
             yield pos
         yield self.predictions(diffused_latents, to_index, positive)

@@ -173,8 +173,6 @@ def test_sample_loop_schedule_and_errors():
         m.random_diffused_latents((1, 3, 500, 512))
     with pytest.raises(ValueError):
         next(m.sample("abc", from_index=500))
-    with pytest.raises(NotImplementedError):
-        models.StableDiffusion("runwayml/stable-diffusion-inpainting")
     with pytest.raises(RuntimeError):
         models.StableDiffusion(weights="pretrained")
 
@@ -240,3 +238,48 @@ def test_sd_predictions_class_vs_reference_class_golden():
     assert close(mk(g["eps"] * 3, slice(0, 1)).latent_dynamic_threshold(0.95).predicted_noise, "latent_thr")
     w = torch.stack([p.wasserstein_distance(), p.wasserstein_square_distance()])
     assert float((w.cpu() - g["wasserstein"]).abs().max()) <= 2e-6
+
+
+def test_inpainting_checkpoint_surface_vs_oracle():
+    """runwayml/stable-diffusion-inpainting: 9-channel UNet input = latents | binarised latent mask | latents of the masked image
+    (conditioning.py:31-40), latent masks (blur + bilinear down-sampling), sample() with replace_diffused.  UNet values against the oracle
+    on the concatenated input; the blur restates kornia's gaussian_blur2d (absent: that helper is parity-unpinned)."""
+    from oracle import sd as osd
+    from perceptor_amd import models
+    from perceptor_amd.engine import sd
+    from perceptor_amd.utils.synth import seeded_noise, synth_state_dict
+    from perceptor_amd.utils.tokenizer import ClipTokenizer
+    cfg = sd.SdConfig(in_channels=9, block_out=(32, 64, 64), cross_attn=(True, True, False), heads=2, context_dim=32)
+    vae = sd.VaeConfig(block_out=(32, 64, 64, 64), layers_per_block=1)            # three down-samplings: latents at 1/8 resolution, as SD
+    m = models.StableDiffusion("runwayml/stable-diffusion-inpainting", config=cfg, vae_config=vae, text_config=TINY_TEXT).to("cuda")
+    img = (seeded_noise((1, 3, 128, 128), 91) * 0.2 + 0.5).clamp(0, 1).cuda()
+    mask = torch.zeros(1, 1, 128, 128).cuda()
+    mask[:, :, :, 48:] = 1.0
+    lm = m.latent_masks(mask, 4.0)
+    assert lm.shape == (1, 1, 16, 16) and float(lm[0, 0, 8, 0]) < 1e-3 and float(lm[0, 0, 8, 15]) > 0.999
+    assert 0.0 < float(lm[0, 0, 8, 5]) < 0.5 < float(lm[0, 0, 8, 6]) < 1.0 and bool((lm[0, 0, 8, 1:] >= lm[0, 0, 8, :-1]).all())     # the edge at pixel 48 = latent column 6, blurred
+    assert torch.equal(m.latent_masks(mask, None), torch.nn.functional.interpolate(mask, size=(16, 16), mode="bilinear"))
+    with pytest.raises(ValueError):
+        m.latent_masks(mask * 2, 4.0)
+    with pytest.raises(ValueError):
+        m.latent_masks(mask.expand(1, 3, 128, 128), 4.0)
+    ids = torch.tensor([[518, 5, 9, 519] + [519] * 12])
+    cond = m.conditioning(token_ids=ids, inpainting_masks=mask, inpainting_images=img)
+    assert cond.inpainting_latents.shape == (1, 4, 16, 16) and cond.inpainting_latent_masks.shape == (1, 1, 16, 16)
+    x = seeded_noise((1, 4, 16, 16), 92).cuda()
+    got = m.predictions(x, 500, cond).predicted_noise.cpu()
+    ocfg = osd.SdConfig(in_channels=9, block_out=(32, 64, 64), cross_attn=(True, True, False), heads=2, context_dim=32)
+    w = synth_state_dict(osd.unet_state_dict_shapes(ocfg), 0)
+    with torch.no_grad():
+        want = osd.unet_forward(w, ocfg, cond.input(x).cpu(), torch.tensor([500]), cond.encodings.float().cpu())
+    emax, el2 = _err(got, want)
+    assert got.shape == (1, 4, 16, 16) and emax < TOL["f16"][0] and el2 < TOL["f16"][1], (emax, el2)
+    m._tokenizer = ClipTokenizer(merges=[("a", "b"), ("ab", "c</w>"), ("c", "a")])
+    outs = list(m.sample("abc", from_index=600, to_index=300, n_steps=4, init_image=img, inpainting_mask=mask, n_resample=1))
+    last = outs[-1]
+    assert last.predicted_noise.shape == (1, 4, 16, 16) and bool(torch.isfinite(last.predicted_noise).all())
+    # replace_diffused: outside the mask the chain follows the (re-noised) original image's latents
+    keep = cond.inpainting_latent_masks < 1e-3
+    init = m.latents(img)
+    a600 = float(m.schedule_alphas[int(last.from_indices[0])])
+    assert bool(keep.any()) and float(((last.from_diffused_latents - init * a600) * keep).abs().max()) < 6.0     # noise-level distance, finite
