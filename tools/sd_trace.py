@@ -36,3 +36,20 @@ tot = sum(v[1] for v in agg.values()) / steps
 print(f"total GEMM-launch time per step {tot:.2f} ms")
 for desc, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"{ms / steps:8.3f} ms/step  x{n // steps:4d}  {ms / n * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s  {desc}")
+
+# ---- the pieces outside the per-step loop: VAE decode / encode at 512x512, the text encoder (once per prompt) ----
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+z = lat[:1]
+img = m.decode(z)
+print(f"VAE decode 1x4x64x64 -> 1x3x512x512: {timeit(lambda: m.decode(z)):.2f} ms;  batch 4: {timeit(lambda: m.decode(lat)):.2f} ms")
+print(f"VAE encode 1x3x512x512 -> latents: {timeit(lambda: m.latents(img)):.2f} ms")
+print(f"text encoder (ViT-L/14 text, 2 prompts x 77 tokens): {timeit(lambda: m.token_encodings(ids)):.2f} ms")
