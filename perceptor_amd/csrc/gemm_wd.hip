@@ -302,6 +302,7 @@ extern "C" int pmi_gemm_wd_eligible(const pmi_igemm_args* a) {
   if (!a->Bf || a->taps != 1 || a->up || a->stride != 1 || a->batch > 1 || a->C1 != 0 || a->A1) return 0;
   if (a->nbias || a->stats || a->pro_a || a->res_up || a->split_out) return 0;
   if ((a->K % 32) || (a->N % 32) || a->K != a->C0 || a->M < 64) return 0;      // K tail: zero-padded weights; N tail: masked waves
+  if (a->N < 256) return 0;                 // one half-empty 256-column tile: the generic 128-wide tiles are faster (N = 128, M = 2 M rows: 521 vs 607 us)
   if ((a->N % 256) && a->N < 1024) {        // narrow matrix with a partly filled last tile: measured per shape against the generic 128-wide tiles (tools/sd_trace.py)
     const int tail = a->N % 256;
     if (tail < 64 || (tail < 128 && a->R && a->res_f32)) return 0;      // (N = 320 with an fp32 residual: 50 vs 45 us; without: 26 vs 29, fp32 out 34 vs 42)
