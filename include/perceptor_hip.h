@@ -133,6 +133,9 @@ int pmi_gn_finalize(const float* s0, int P0, int C0, const float* s1, int P1, in
 /* res: optional 16-bit NHWC tensor added after the activation (cc12m_1.py:46-61: relu(mod(norm(conv))) + skip) */
 int pmi_gn_apply(const void* x, const void* x1, int C0, const float* coef_a, const float* coef_b, const void* res, void* y, int N, int H, int W, int C,
                  int act, int pool, int dtype, pmi_stream_t s);
+/* the down ResBlock's two pooled tensors from ONE pass over x (unet.py:232-243: h = AvgPool(SiLU(GN(x))), skip = AvgPool(x)) */
+int pmi_gn_apply_pool_skip(const void* x, const float* coef_a, const float* coef_b, void* y, void* y_raw, int N, int H, int W, int C, int act,
+                           int dtype, pmi_stream_t s);
 
 /* ---- attention, head dim 64 (flash-style, MFMA) -----------------------------------
  * unet.py:332-348 (QKVAttentionLegacy), :364-382 (QKVAttention), yfcc_2.py:62-70.

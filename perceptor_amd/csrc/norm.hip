@@ -134,18 +134,22 @@ __global__ __launch_bounds__(256) void gn_finalize2_kernel(const float* __restri
 }
 
 template <typename T>
-__device__ __forceinline__ void affine_act8(const u16* row, int c, int C, const float* a, const float* b, int act, float* out, float w) {
+__device__ __forceinline__ void affine_act8(const u16* row, int c, int C, const float* a, const float* b, int act, float* out, float w, float* raw = nullptr) {
   float f[8];
   load8<T>(row, c, C, f);
 #pragma unroll
   for (int e = 0; e < 8; ++e) out[e] += w * act_apply(f[e] * a[e] + b[e], act);
+  if (raw) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) raw[e] += w * f[e];
+  }
 }
 
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const u16* __restrict__ x, const u16* __restrict__ x1, int C0,
                                                        const float* __restrict__ ca, const float* __restrict__ cb,
                                                        const u16* __restrict__ res, u16* __restrict__ y, int N, int H, int W,
-                                                       int C, int act) {
+                                                       int C, int act, u16* __restrict__ y_raw = nullptr) {
   const int C8 = C >> 3;
   const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
   const int64_t total = (int64_t)N * Ho * Wo * C8;
@@ -168,10 +172,15 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const u16* __restrict__ x
       const int rem = (int)(pix - (int64_t)n * Ho * Wo);
       const int oy = rem / Wo, ox = rem - oy * Wo;
       const u16* base = src + (((int64_t)n * H + 2 * oy) * W + 2 * ox) * ld;
-      affine_act8<T>(base, cl, Cs, a, b, act, o, 0.25f);
-      affine_act8<T>(base + ld, cl, Cs, a, b, act, o, 0.25f);
-      affine_act8<T>(base + (int64_t)W * ld, cl, Cs, a, b, act, o, 0.25f);
-      affine_act8<T>(base + (int64_t)W * ld + ld, cl, Cs, a, b, act, o, 0.25f);
+      float rw[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) rw[e] = 0.f;
+      float* const rp = y_raw ? rw : nullptr;          // the down ResBlock's skip path: AvgPool2d(2) of the RAW input, same four reads
+      affine_act8<T>(base, cl, Cs, a, b, act, o, 0.25f, rp);
+      affine_act8<T>(base + ld, cl, Cs, a, b, act, o, 0.25f, rp);
+      affine_act8<T>(base + (int64_t)W * ld, cl, Cs, a, b, act, o, 0.25f, rp);
+      affine_act8<T>(base + (int64_t)W * ld + ld, cl, Cs, a, b, act, o, 0.25f, rp);
+      if (y_raw) store8<T>(y_raw + pix * row_elems<T>(C), c8 * 8, C, rw);
     } else {
       affine_act8<T>(src + pix * ld, cl, Cs, a, b, act, o, 1.f);
     }
@@ -240,10 +249,26 @@ extern "C" int pmi_gn_apply(const void* x, const void* x1, int C0, const float* 
   const int64_t work = (int64_t)N * (pool ? H / 2 : H) * (pool ? W / 2 : W) * (C / 8);
   dim3 grid(grid_for(work)), block(256);
   hipStream_t st = (hipStream_t)s;
-#define GO(TT, PP) hipLaunchKernelGGL((gn_apply_kernel<TT, PP>), grid, block, 0, st, (const u16*)x, (const u16*)x1, C0, coef_a, coef_b, (const u16*)res, (u16*)y, N, H, W, C, act)
+#define GO(TT, PP) hipLaunchKernelGGL((gn_apply_kernel<TT, PP>), grid, block, 0, st, (const u16*)x, (const u16*)x1, C0, coef_a, coef_b, (const u16*)res, (u16*)y, N, H, W, C, act, (u16*)nullptr)
   if (dtype == PMI_DT_BF16) { if (pool) GO(BF16, true); else GO(BF16, false); }
   else if (dtype == PMI_DT_F16X2) { if (pool) GO(F16X2, true); else GO(F16X2, false); }
   else { if (pool) GO(F16, true); else GO(F16, false); }
+#undef GO
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+
+// the down ResBlock's two pooled tensors from one pass over x (unet.py:232-243): y = AvgPool2d(2)(act(x * a + b)) and y_raw = AvgPool2d(2)(x)
+extern "C" int pmi_gn_apply_pool_skip(const void* x, const float* coef_a, const float* coef_b, void* y, void* y_raw, int N, int H, int W, int C,
+                                      int act, int dtype, pmi_stream_t s) {
+  if (!x || !y || !y_raw || !coef_a || !coef_b || N <= 0 || H <= 0 || W <= 0 || (C & 7) || (H & 1) || (W & 1)) return PMI_ERR_ARG;
+  const int64_t work = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
+  dim3 grid(grid_for(work)), block(256);
+  hipStream_t st = (hipStream_t)s;
+#define GO(TT) hipLaunchKernelGGL((gn_apply_kernel<TT, true>), grid, block, 0, st, (const u16*)x, (const u16*)nullptr, C, coef_a, coef_b, (const u16*)nullptr, (u16*)y, N, H, W, C, act, (u16*)y_raw)
+  if (dtype == PMI_DT_BF16) GO(BF16);
+  else if (dtype == PMI_DT_F16X2) GO(F16X2);
+  else GO(F16);
 #undef GO
   PMI_CHECK_LAUNCH();
   return PMI_OK;

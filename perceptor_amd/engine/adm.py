@@ -218,8 +218,11 @@ class AdmEngine:
         skip, skip1 = x, x1
         if l.down:
             # SiLU(GN(x)) must be pooled AFTER the activation: streaming apply+pool kernel, then the conv
-            h = ops.group_norm(x, g1, b1, 32, dt, x1=x1, act=ACT_SILU, pool=True)
-            skip = ops.avgpool2(x, dt)
+            if x1 is None:      # both pooled tensors from one pass over x
+                h, skip = ops.group_norm_pool_skip(x, g1, b1, 32, dt, act=ACT_SILU)
+            else:
+                h = ops.group_norm(x, g1, b1, 32, dt, x1=x1, act=ACT_SILU, pool=True)
+                skip = ops.avgpool2(x, dt)
             h = ops.igemm(h, w[l.p + ".conv1"], nbias=nb, want_stats=True)
         else:
             # GroupNorm-apply + SiLU fused into the conv's patch staging (no activated copy in HBM)

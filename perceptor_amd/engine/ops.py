@@ -368,6 +368,17 @@ def group_norm(x: torch.Tensor, gamma, beta, groups: int, dt: int, *, x1: Option
     return y
 
 
+def group_norm_pool_skip(x: torch.Tensor, gamma, beta, groups: int, dt: int, act: int = ACT_NONE, eps: float = 1e-5):
+    """(AvgPool2d(2)(act(GroupNorm(x))), AvgPool2d(2)(x)) from one pass over x: both inputs of a down ResBlock (unet.py:232-243)."""
+    n, h, w, _ = x.shape
+    c = logical_c(x, dt)
+    ca, cb = _gn_coeffs(x, None, gamma, beta, groups, dt, None, 0, eps)
+    y = _empty((n, h // 2, w // 2, x.shape[-1]), x.dtype, x.device)
+    y_raw = _empty((n, h // 2, w // 2, x.shape[-1]), x.dtype, x.device)
+    call("pmi_gn_apply_pool_skip", ptr(x), ptr(ca), ptr(cb), ptr(y), ptr(y_raw), n, h, w, c, act, dt)
+    return y, y_raw
+
+
 def avgpool2(x: torch.Tensor, dt: int) -> torch.Tensor:
     n, h, w, c = x.shape
     y = _empty((n, h // 2, w // 2, c), x.dtype, x.device)
