@@ -20,7 +20,9 @@
 
 namespace {
 
-template <typename T, int MB>
+// TWO: the K dimension is the concatenation of two activation tensors (A0: C0 channels, A1: C1; C0 a multiple of 128) -- the 1x1
+// `skip_connection` of a ResBlock whose input is a skip concat (th.cat([h, hs.pop()]), unet.py:647-650), never materialised.
+template <typename T, int MB, bool TWO = false>
 __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a) {
   constexpr int TM = 16 * MB, BN = 256, BK = 128, NT = 512;
   constexpr int ROW = 2 * BK + 32;                     // LDS row pitch (bytes)
@@ -53,12 +55,16 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
 
   // activation rows of this tile: rows past M fall outside the resource (zeros)
   const int rows = min(TM, a.M - m0);
-  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc((const u16*)a.A0 + (int64_t)m0 * a.lda0, ((int64_t)(rows - 1) * a.lda0 + a.K) * 2);
+  const int K0 = TWO ? a.C0 : a.K;                      // channels of the first source
+  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc((const u16*)a.A0 + (int64_t)m0 * a.lda0, ((int64_t)(rows - 1) * a.lda0 + K0) * 2);
+  const __amdgpu_buffer_rsrc_t rsrc_a1 = TWO ? make_rsrc((const u16*)a.A1 + (int64_t)m0 * a.lda1, ((int64_t)(rows - 1) * a.lda1 + a.C1) * 2) : rsrc_a;
   uint32_t pvo[NPI];                                    // byte offset of this thread's staging pieces inside the tile's rows (k = 0)
+  uint32_t pvo1[TWO ? NPI : 1];                         // the same for the second source's row pitch
 #pragma unroll
   for (int i = 0; i < NPI; ++i) {
     const int p = tid + NT * i, r = p >> 4, c16 = p & 15;
     pvo[i] = r < rows ? (uint32_t)(r * a.lda0 + c16 * 8) * 2u : PMI_BUF_OOB;
+    if constexpr (TWO) pvo1[i] = r < rows ? (uint32_t)(r * a.lda1 + c16 * 8) * 2u : PMI_BUF_OOB;
   }
   // this wave's weight stream: [chunk][k32 (4)][16-column block (2)][lane][8], 8 KB per chunk, contiguous
   const int64_t wslab = (int64_t)nch_all * 8192;
@@ -68,8 +74,17 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
 
   uint4 pr[NPI];
   auto load_tile = [&](int chunk, bool live) {
+    if constexpr (TWO) {
+      const int k0 = (c0 + chunk) * BK;                 // wave-uniform: which tensor this 128-deep chunk comes from (C0 is a multiple of 128)
+      const bool second = k0 >= a.C0;
+      const __amdgpu_buffer_rsrc_t rs = second ? rsrc_a1 : rsrc_a;
+      const uint32_t so = (uint32_t)(second ? k0 - a.C0 : k0) * 2u;
 #pragma unroll
-    for (int i = 0; i < NPI; ++i) pr[i] = buf_load16(rsrc_a, live ? pvo[i] : PMI_BUF_OOB, (uint32_t)(c0 + chunk) * (BK * 2));
+      for (int i = 0; i < NPI; ++i) pr[i] = buf_load16(rs, live ? (second ? pvo1[i] : pvo[i]) : PMI_BUF_OOB, so);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPI; ++i) pr[i] = buf_load16(rsrc_a, live ? pvo[i] : PMI_BUF_OOB, (uint32_t)(c0 + chunk) * (BK * 2));
+    }
   };
   auto store_tile = [&](char* buf) {
 #pragma unroll
@@ -277,7 +292,8 @@ template <typename T>
 int launch(const pmi_igemm_args& a, hipStream_t s, int mb) {
   const int tm = 16 * mb;
   const dim3 grid(((a.M + tm - 1) / tm) * ((a.N + 255) / 256), 1, a.splitk > 1 ? a.splitk : 1);
-  if (mb == 9) hipLaunchKernelGGL((gemm_wd_kernel<T, 9>), grid, dim3(512), 0, s, a);
+  if (a.A1) hipLaunchKernelGGL((gemm_wd_kernel<T, 8, true>), grid, dim3(512), 0, s, a);        // two-source K: 128-row tiles
+  else if (mb == 9) hipLaunchKernelGGL((gemm_wd_kernel<T, 9>), grid, dim3(512), 0, s, a);
   else hipLaunchKernelGGL((gemm_wd_kernel<T, 8>), grid, dim3(512), 0, s, a);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
@@ -287,6 +303,7 @@ int launch(const pmi_igemm_args& a, hipStream_t s, int mb) {
 
 // rows per tile (128 or 144): fewest rounds of 256 workgroups, then least work per workgroup
 int pmi_gemm_wd_tile_rows(const pmi_igemm_args* a, int splitk) {
+  if (a->A1) return 128;
   int best = 8;
   long best_cost = -1;
   for (int mb = 8; mb <= 9; ++mb) {
@@ -299,9 +316,10 @@ int pmi_gemm_wd_tile_rows(const pmi_igemm_args* a, int splitk) {
 
 // 1 when the weights-direct GEMM takes this call (plain GEMM with fragment-ordered weights), else the generic kernel runs
 extern "C" int pmi_gemm_wd_eligible(const pmi_igemm_args* a) {
-  if (!a->Bf || a->taps != 1 || a->up || a->stride != 1 || a->batch > 1 || a->C1 != 0 || a->A1) return 0;
+  if (!a->Bf || a->taps != 1 || a->up || a->stride != 1 || a->batch > 1) return 0;
+  if (a->A1 ? (a->C1 <= 0 || (a->C0 % 128) || (a->C1 % 32) || a->splitk > 1 || a->D2 || a->aux || a->act == PMI_ACT_GEGLU) : a->C1 != 0) return 0;
   if (a->nbias || a->stats || a->pro_a || a->res_up || a->split_out) return 0;
-  if ((a->K % 32) || (a->N % 32) || a->K != a->C0 || a->M < 64) return 0;      // K tail: zero-padded weights; N tail: masked waves
+  if ((a->K % 32) || (a->N % 32) || a->K != a->C0 + a->C1 || a->M < 64) return 0;      // K tail: zero-padded weights; N tail: masked waves
   if (a->N < 256) return 0;                 // one half-empty 256-column tile: the generic 128-wide tiles are faster (N = 128, M = 2 M rows: 521 vs 607 us)
   if ((a->N % 256) && a->N < 1024) {        // narrow matrix with a partly filled last tile: measured per shape against the generic 128-wide tiles (tools/sd_trace.py)
     const int tail = a->N % 256;

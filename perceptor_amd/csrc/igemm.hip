@@ -550,6 +550,7 @@ extern "C" int pmi_igemm_splitk(const pmi_igemm_args* a) {
   if (a->batch > 1 || (a->N & 3)) return 1;
   if (g_allow_halo && pmi_conv3x3_halo_config(a) >= 0) return 1;
   if (a->act == PMI_ACT_GEGLU) return 1;
+  if (a->A1 && pmi_gemm_wd_eligible(a)) return 1;       // two-source weights-direct GEMM: no split-K
   if (pmi_gemm_wd_eligible(a)) {    // weights-direct GEMM: fill the 256 CUs with (row tile x 256-column) workgroups; >= 2 chunks of 128 per split
     const int nch = (a->K + 127) / 128;
     int best = 1;

@@ -208,7 +208,7 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
         a.Bf = ptr(lin.frag16(64)) if cfg == 6 else ptr(lin.frag16(32)) if cfg == 7 else ptr(lin.frag(64)) if cfg == 4 else None
     if pre_out is not None or act_grad_of is not None:
         a.D2, a.aux, a.aux_act = ptr(pre_out), ptr(act_grad_of), act_grad
-    if GEMM_WD_ENABLED and lin.taps == 1 and not lin.split and not up and stride == 1 and a1 is None and lin.n_p % 32 == 0 and lin.K % 32 == 0 \
+    if GEMM_WD_ENABLED and lin.taps == 1 and not lin.split and not up and stride == 1 and lin.n_p % 32 == 0 and lin.K % 32 == 0 \
             and nbias is None and not want_stats and prologue is None:
         a.Bf = 1                               # plain GEMM: ask whether the weights-direct kernel (csrc/gemm_wd.hip) takes this shape ...
         a.Bf = ptr(lin.frag_gemm()) if _hip.lib().pmi_gemm_wd_eligible(C.byref(a)) else None      # ... and only then pack its weight order

@@ -45,6 +45,9 @@ def _check(got, ref, dtype, extra=1.0):
     dict(n=2, h=8, w=12, cin=64, cout=64, k=3, res_up=True),  # up ResBlock tail: residual = nearest-up(skip)
     dict(n=1, h=16, w=16, cin=64, cout=72, k=3, stride=2),
     dict(n=2, h=8, w=8, cin=128, cout=256, k=1),
+    dict(n=2, h=16, w=16, cin=384, cout=256, k=1, split=256),   # ResBlock skip_connection over a skip concat: two-source weights-direct GEMM
+    dict(n=3, h=8, w=24, cin=768, cout=512, k=1, split=512),
+    dict(n=1, h=16, w=16, cin=224, cout=320, k=1, split=128),   # second source with a K tail (96 channels), N tail
     dict(n=1, h=32, w=32, cin=128, cout=6, k=3, f32=True),  # output conv: 6 channels padded to 8, fp32 out
     # LDS-halo conv3x3 kernel (W % 32 == 0, Cin % 64 == 0): both tile configs, borders, concat, up, residual-up
     dict(n=2, h=16, w=32, cin=64, cout=128, k=3, force_cfg=1),
