@@ -22,13 +22,15 @@ namespace {
 
 // TWO: the K dimension is the concatenation of two activation tensors (A0: C0 channels, A1: C1; C0 a multiple of 128) -- the 1x1
 // `skip_connection` of a ResBlock whose input is a skip concat (th.cat([h, hs.pop()]), unet.py:647-650), never materialised.
-template <typename T, int MB, bool TWO = false>
-__global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a) {
-  constexpr int TM = 16 * MB, BN = 256, BK = 128, NT = 512;
+// NWV: waves per workgroup = 32-column slices per tile: 8 (256-column tiles) or 4 (128-column tiles, 256 threads: N = 128, where a 256-column
+// tile would run half its waves on zeros).
+template <typename T, int MB, bool TWO = false, int NWV = 8>
+__global__ __launch_bounds__(NWV * 64, 2) void gemm_wd_kernel(const pmi_igemm_args a) {
+  constexpr int TM = 16 * MB, BN = NWV * 32, BK = 128, NT = NWV * 64;
   constexpr int ROW = 2 * BK + 32;                     // LDS row pitch (bytes)
   constexpr int TILE = TM * ROW;
   constexpr int NPI = (TM * 16 + NT - 1) / NT;         // 16-byte staging pieces per thread per chunk
-  constexpr int HIMG = TM * (256 * 2 + 16);            // one 16-bit epilogue image of the tile
+  constexpr int HIMG = TM * (BN * 2 + 16);             // one 16-bit epilogue image of the tile
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE > 2 * HIMG ? 2 * TILE : 2 * HIMG];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
   // this wave's weight stream: [chunk][k32 (4)][16-column block (2)][lane][8], 8 KB per chunk, contiguous
   const int64_t wslab = (int64_t)nch_all * 8192;
   const bool wave_live = n0 + wid * 32 < a.N;          // wave-uniform; a dead wave's weight resource is empty (every load returns zeros)
-  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc((const char*)a.Bf + (wave_live ? (int64_t)(tn * 8 + wid) * wslab : 0), wave_live ? wslab : 0);
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc((const char*)a.Bf + (wave_live ? (int64_t)(tn * NWV + wid) * wslab : 0), wave_live ? wslab : 0);
   const uint32_t wvo = (uint32_t)lane * 16u + (uint32_t)c0 * 8192u;
 
   uint4 pr[NPI];
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
     // ---- GEGLU epilogue (stable_diffusion/attention.py:346-348): the weights are packed so that every wave's 32 columns are 16 value
     // columns (block 0) and their 16 gate columns (block 1): out = value * gelu(gate), 128 output columns per tile, through a 16-bit
     // LDS image and out as 256-byte rows.  The 8C-wide projection never exists in HBM. ----
-    constexpr int GROW = 128 * 2 + 16;
+    constexpr int GROW = (BN / 2) * 2 + 16;
     const int cl = wid * 16 + 4 * (lane >> 4);           // output column inside the tile
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
     if (a.bias && wave_live) { bv = *(const float4*)(a.bias + n0 + wid * 32 + 4 * (lane >> 4)); bg = *(const float4*)(a.bias + n0 + wid * 32 + 16 + 4 * (lane >> 4)); }
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
       *(uint2*)(smem + (mb * 16 + (lane & 15)) * GROW + cl * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
     }
     __syncthreads();
-    const int gc8 = tid & 15, grow = tid >> 4;           // 8 columns (16 B) x rows grow + 32 j
+    const int gc8 = tid % (BN / 16), grow = tid / (BN / 16);     // 8 columns (16 B) x rows grow + 32 j
     const int nh = a.N >> 1, nh0 = n0 >> 1;
 #pragma unroll
     for (int j = 0; j < (TM + 31) / 32; ++j) {
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
   if (!raw && !a.out_f32 && !(a.R && a.res_f32)) {
     // ---- epilogue, 16-bit output: ONE pass through a 16-bit image of the whole tile (bias + activation applied on the way in),
     // written out as 512-byte rows, 16 bytes per lane; a 16-bit residual is added on the way out ----
-    constexpr int HROW = 256 * 2 + 16;
+    constexpr int HROW = BN * 2 + 16;
     static_assert(2 * TM * HROW <= 160 * 1024, "the two 16-bit epilogue images (output, pre-activation) must fit the LDS");
     act_switch(a.act, [&](auto act_c) __attribute__((always_inline)) {    // element loops compiled per activation (no per-value switch)
       constexpr int ACT = decltype(act_c)::value;
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
     });
     __syncthreads();
     const bool d2_img = a.D2 && a.act != PMI_ACT_NONE;   // without an activation the second output equals the first
-    const int pc8 = tid & 31, prow = tid >> 5;         // 8 columns (16 B) x rows prow + 16 j
+    const int pc8 = tid % (BN / 8), prow = tid / (BN / 8);     // 8 columns (16 B) x rows prow + 16 j
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
       const int r = prow + 16 * j, m = m0 + r;
@@ -291,6 +293,13 @@ __global__ __launch_bounds__(512, 2) void gemm_wd_kernel(const pmi_igemm_args a)
 template <typename T>
 int launch(const pmi_igemm_args& a, hipStream_t s, int mb) {
   const int tm = 16 * mb;
+  if (a.N < 256) {                                     // 128-column tiles, four waves, two workgroups per CU
+    const dim3 g4(((a.M + 127) / 128) * ((a.N + 127) / 128), 1, a.splitk > 1 ? a.splitk : 1);
+    if (a.A1) hipLaunchKernelGGL((gemm_wd_kernel<T, 8, true, 4>), g4, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_wd_kernel<T, 8, false, 4>), g4, dim3(256), 0, s, a);
+    PMI_CHECK_LAUNCH();
+    return PMI_OK;
+  }
   const dim3 grid(((a.M + tm - 1) / tm) * ((a.N + 255) / 256), 1, a.splitk > 1 ? a.splitk : 1);
   if (a.A1) hipLaunchKernelGGL((gemm_wd_kernel<T, 8, true>), grid, dim3(512), 0, s, a);        // two-source K: 128-row tiles
   else if (mb == 9) hipLaunchKernelGGL((gemm_wd_kernel<T, 9>), grid, dim3(512), 0, s, a);
@@ -303,7 +312,7 @@ int launch(const pmi_igemm_args& a, hipStream_t s, int mb) {
 
 // rows per tile (128 or 144): fewest rounds of 256 workgroups, then least work per workgroup
 int pmi_gemm_wd_tile_rows(const pmi_igemm_args* a, int splitk) {
-  if (a->A1) return 128;
+  if (a->A1 || a->N < 256) return 128;
   int best = 8;
   long best_cost = -1;
   for (int mb = 8; mb <= 9; ++mb) {
@@ -320,7 +329,7 @@ extern "C" int pmi_gemm_wd_eligible(const pmi_igemm_args* a) {
   if (a->A1 ? (a->C1 <= 0 || (a->C0 % 128) || (a->C1 % 32) || a->splitk > 1 || a->D2 || a->aux || a->act == PMI_ACT_GEGLU) : a->C1 != 0) return 0;
   if (a->nbias || a->stats || a->pro_a || a->res_up || a->split_out) return 0;
   if ((a->K % 32) || (a->N % 32) || a->K != a->C0 + a->C1 || a->M < 64) return 0;      // K tail: zero-padded weights; N tail: masked waves
-  if (a->N < 256) return 0;                 // one half-empty 256-column tile: the generic 128-wide tiles are faster (N = 128, M = 2 M rows: 521 vs 607 us)
+  if (a->N < 256 && a->N != 128) return 0;  // N = 128: the four-wave 128-column tiles; other narrow matrices stay on the generic kernel
   if ((a->N % 256) && a->N < 1024) {        // narrow matrix with a partly filled last tile: measured per shape against the generic 128-wide tiles (tools/sd_trace.py)
     const int tail = a->N % 256;
     if (tail < 64 || (tail < 128 && a->R && a->res_f32)) return 0;      // (N = 320 with an fp32 residual: 50 vs 45 us; without: 26 vs 29, fp32 out 34 vs 42)

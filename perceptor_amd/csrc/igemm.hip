@@ -557,7 +557,7 @@ extern "C" int pmi_igemm_splitk(const pmi_igemm_args* a) {
     long best_cost = -1;
     for (int s = 1; s <= 8 && nch / s >= 4; s *= 2) {
       const int rows = pmi_gemm_wd_tile_rows(a, s);
-      const long wgs = (long)((a->M + rows - 1) / rows) * ((a->N + 255) / 256) * s;
+      const long wgs = (long)((a->M + rows - 1) / rows) * (a->N < 256 ? 1 : (a->N + 255) / 256) * s;
       // rounds x rows x (chunks + fixed prologue / epilogue share); a split pays for its fp32 slabs and the reduce launch
       const long cost = ((wgs + 255) / 256) * rows * (nch / s + 6) + (s > 1 ? 8L * 144 : 0);
       if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = s; }

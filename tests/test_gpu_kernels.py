@@ -48,6 +48,7 @@ def _check(got, ref, dtype, extra=1.0):
     dict(n=2, h=16, w=16, cin=384, cout=256, k=1, split=256),   # ResBlock skip_connection over a skip concat: two-source weights-direct GEMM
     dict(n=3, h=8, w=24, cin=768, cout=512, k=1, split=512),
     dict(n=1, h=16, w=16, cin=224, cout=320, k=1, split=128),   # second source with a K tail (96 channels), N tail
+    dict(n=2, h=16, w=16, cin=384, cout=128, k=1, split=256),   # Cout = 128: the four-wave 128-column tiles, two sources
     dict(n=1, h=32, w=32, cin=128, cout=6, k=3, f32=True),  # output conv: 6 channels padded to 8, fp32 out
     # LDS-halo conv3x3 kernel (W % 32 == 0, Cin % 64 == 0): both tile configs, borders, concat, up, residual-up
     dict(n=2, h=16, w=32, cin=64, cout=128, k=3, force_cfg=1),
@@ -162,6 +163,8 @@ def test_igemm_linear_ragged_and_nbias(dtype):
     dict(m=1000, k=640, n=1920, act=3),                           # both tails, ragged rows
     dict(m=2048, k=2560, n=640, res="f32"),                       # fp32 residual, 16-bit out (the transformer blocks' last feed-forward GEMM), N tail
     dict(m=333, k=1280, n=1184, f32=True, res="f32"),             # N = 37 blocks of 32, fp32 out
+    dict(m=5000, k=256, n=128, res="16"),                         # N = 128: four-wave 128-column tiles (256 threads, two workgroups per CU)
+    dict(m=700, k=384, n=128, act=3, f32=True),
 ])
 def test_gemm_wd(case, dtype):
     """Weights-direct GEMM (csrc/gemm_wd.hip) against fp32 torch on operands pre-rounded to the compute type."""
