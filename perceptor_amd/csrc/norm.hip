@@ -133,19 +133,19 @@ __global__ __launch_bounds__(256) void gn_finalize2_kernel(const float* __restri
   gn_coeffs_out(tot[0], tot[1], n, g, C, cpg, HW, eps, gamma, beta, film, film_ld, ca, cb, tid);
 }
 
-template <typename T>
+template <typename T, bool RAW = false>
 __device__ __forceinline__ void affine_act8(const u16* row, int c, int C, const float* a, const float* b, int act, float* out, float w, float* raw = nullptr) {
   float f[8];
   load8<T>(row, c, C, f);
 #pragma unroll
   for (int e = 0; e < 8; ++e) out[e] += w * act_apply(f[e] * a[e] + b[e], act);
-  if (raw) {
+  if constexpr (RAW) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) raw[e] += w * f[e];
   }
 }
 
-template <typename T, bool POOL>
+template <typename T, bool POOL, bool RAW = false>      // RAW (with POOL): second output = the 2x2 average of the raw input
 __global__ __launch_bounds__(256) void gn_apply_kernel(const u16* __restrict__ x, const u16* __restrict__ x1, int C0,
                                                        const float* __restrict__ ca, const float* __restrict__ cb,
                                                        const u16* __restrict__ res, u16* __restrict__ y, int N, int H, int W,
@@ -172,15 +172,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const u16* __restrict__ x
       const int rem = (int)(pix - (int64_t)n * Ho * Wo);
       const int oy = rem / Wo, ox = rem - oy * Wo;
       const u16* base = src + (((int64_t)n * H + 2 * oy) * W + 2 * ox) * ld;
-      float rw[8];
+      float rw[8];                                     // the down ResBlock's skip path: AvgPool2d(2) of the RAW input, same four reads
 #pragma unroll
       for (int e = 0; e < 8; ++e) rw[e] = 0.f;
-      float* const rp = y_raw ? rw : nullptr;          // the down ResBlock's skip path: AvgPool2d(2) of the RAW input, same four reads
-      affine_act8<T>(base, cl, Cs, a, b, act, o, 0.25f, rp);
-      affine_act8<T>(base + ld, cl, Cs, a, b, act, o, 0.25f, rp);
-      affine_act8<T>(base + (int64_t)W * ld, cl, Cs, a, b, act, o, 0.25f, rp);
-      affine_act8<T>(base + (int64_t)W * ld + ld, cl, Cs, a, b, act, o, 0.25f, rp);
-      if (y_raw) store8<T>(y_raw + pix * row_elems<T>(C), c8 * 8, C, rw);
+      affine_act8<T, RAW>(base, cl, Cs, a, b, act, o, 0.25f, rw);
+      affine_act8<T, RAW>(base + ld, cl, Cs, a, b, act, o, 0.25f, rw);
+      affine_act8<T, RAW>(base + (int64_t)W * ld, cl, Cs, a, b, act, o, 0.25f, rw);
+      affine_act8<T, RAW>(base + (int64_t)W * ld + ld, cl, Cs, a, b, act, o, 0.25f, rw);
+      if constexpr (RAW) store8<T>(y_raw + pix * row_elems<T>(C), c8 * 8, C, rw);
     } else {
       affine_act8<T>(src + pix * ld, cl, Cs, a, b, act, o, 1.f);
     }
@@ -265,7 +264,7 @@ extern "C" int pmi_gn_apply_pool_skip(const void* x, const float* coef_a, const 
   const int64_t work = (int64_t)N * (H / 2) * (W / 2) * (C / 8);
   dim3 grid(grid_for(work)), block(256);
   hipStream_t st = (hipStream_t)s;
-#define GO(TT) hipLaunchKernelGGL((gn_apply_kernel<TT, true>), grid, block, 0, st, (const u16*)x, (const u16*)nullptr, C, coef_a, coef_b, (const u16*)nullptr, (u16*)y, N, H, W, C, act, (u16*)y_raw)
+#define GO(TT) hipLaunchKernelGGL((gn_apply_kernel<TT, true, true>), grid, block, 0, st, (const u16*)x, (const u16*)nullptr, C, coef_a, coef_b, (const u16*)nullptr, (u16*)y, N, H, W, C, act, (u16*)y_raw)
   if (dtype == PMI_DT_BF16) GO(BF16);
   else if (dtype == PMI_DT_F16X2) GO(F16X2);
   else GO(F16);
