@@ -56,6 +56,7 @@ def parse():
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "precise"],
                    help="UNet arithmetic: bf16 / f16 single-pass MFMA, or precise (hi + lo f16 pairs, eps max-abs error < 1e-3 vs the fp32 reference)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--opt", default="", help="A/B switches of the library: comma-separated key=value pairs for pmi_set_option (e.g. 10=0: no conv split-K)")
     p.add_argument("--sd-bf16", action="store_true", help="config c4: bf16 operands instead of the f16 the reference runs SD in")
     p.add_argument("--no-kernel-events", action="store_true")
     p.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (helps launch-bound small configs such as c1)")
@@ -288,6 +289,11 @@ def main():
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {a.gpus}")
     if a.rehearse:
         raise SystemExit(rehearse(a, rank, local_rank, world))
+    if a.opt:
+        from perceptor_amd import _hip
+        for kv in a.opt.split(","):
+            k, v = kv.split("=")
+            _hip.lib().pmi_set_option(int(k), int(v))
     torch.cuda.set_device(local_rank)            # before the process group: RCCL binds its communicator to the current device
     dev = torch.device("cuda", local_rank)
     dist = None

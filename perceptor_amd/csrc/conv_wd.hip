@@ -42,7 +42,8 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // workgroups share a CU and one's prologue / epilogue runs under the other's main loop (config 7; 16x16x32 MFMA only).
 // SPL: precise mode (dtype 2): the output (and a residual) are hi + lo f16 pairs, [C/32][hi 32 | lo 32] per pixel (common.h: F16X2); the
 // input needs nothing special -- its 2C physical channels are an ordinary K dimension against duplicated weights.
-template <typename T, int PRO, bool MF16, int NWN = 8, int CK = 64, bool SPL = false>
+// SK: split-K over grid.z (its own instantiation: the chunk-range variables cost the unsplit kernel registers it does not have)
+template <typename T, int PRO, bool MF16, int NWN = 8, int CK = 64, bool SPL = false, bool SK = false>
 __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm_args a) {
   constexpr int NW = NWN, NT = NW * 64;
   constexpr int KS = MF16 ? CK / 32 : CK / 16;         // k-steps (one MFMA deep) per chunk
@@ -96,6 +97,10 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
   STAMP(0);
   const int Cin = a.C0 + a.C1;
   const int nchunks = Cin / CK;
+  // split-K (grid.z): this workgroup reduces chunks [cb0, ce) and leaves raw fp32 sums in its slab of a.ws (maps too small to fill the chip
+  // with output tiles alone: 32x32 at batch 8); bias / activation / residual then happen in splitk_reduce_kernel (igemm.hip)
+  const int nsplit = SK ? a.splitk : 1;
+  const int cb0 = SK ? (nchunks / nsplit) * blockIdx.z : 0, ce = SK ? cb0 + nchunks / nsplit : nchunks, nloc = ce - cb0;
   const int sc = tid % CPR;                            // 16-byte chunk (8 channels) of a patch pixel this thread stages
   const int64_t img_px = (int64_t)a.Hin * a.Win;
   const u16* const A0i = (const u16*)a.A0 + (int64_t)img * img_px * a.lda0;
@@ -167,20 +172,20 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
   };
 
   // ---- prologue: patch of chunk 0, the first weight groups ----
-  load_wg(0, 0);
-  if (!MF16) load_wg(1, 1);
+  load_wg(0, cb0 * WGC);
+  if (!MF16) load_wg(1, cb0 * WGC + 1);
   {
     uint4 p0[NPI];
     float ga[8], gb[8];
 #pragma unroll
-    for (int i = 0; i < NPI; ++i) p0[i] = load_piece(0, ppix_s[i * NT + tid], true);      // (a thread reads only its own table entries)
+    for (int i = 0; i < NPI; ++i) p0[i] = load_piece(cb0, ppix_s[i * NT + tid], true);    // (a thread reads only its own table entries)
     if (PRO) {
       for (int c = tid; c < Cin; c += NT) {
         coef[c] = a.pro_a[(int64_t)img * Cin + c];
         coef[MAXCIN + c] = a.pro_b[(int64_t)img * Cin + c];
       }
       __syncthreads();
-      read_coef(0, ga, gb);
+      read_coef(cb0, ga, gb);
     }
 #pragma unroll
     for (int i = 0; i < NPI; ++i) store_piece(smem, i, p0[i], ppix_s[i * NT + tid], ga, gb);
@@ -209,22 +214,22 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
   // carried staging state: the piece waiting for its store slot, its source pixel, and the source pixel of the next load.
   // Table reads (ppix_s, coef) are issued a phase before their use, so their waits are counted lgkmcnt(N), not drains.
   int pixc = ppix_s[0 * NT + tid];
-  uint4 pr = load_piece(nchunks > 1 ? 1 : 0, pixc, nchunks > 1);      // piece 0 of the second chunk's patch
+  uint4 pr = load_piece(nloc > 1 ? cb0 + 1 : cb0, pixc, nloc > 1);    // piece 0 of the second chunk's patch
   int pixn = ppix_s[1 * NT + tid];
   // With an odd number of weight groups per chunk (CK = 32: 3) the two-slot weight ring changes phase from chunk to chunk; the ring slot
   // must be a compile-time register index, so the chunk body is unrolled over both phases and the loop advances two chunks at a time
   // (Cin is a multiple of 64: the chunk count is even).
   constexpr int CSTEP = (MF16 && (WGC & 1)) ? 2 : 1;
-  for (int chunk0 = 0; chunk0 < nchunks; chunk0 += CSTEP) {
+  for (int chunk0 = cb0; chunk0 < ce; chunk0 += CSTEP) {
 #pragma unroll
    for (int ph = 0; ph < CSTEP; ++ph) {                  // fully unrolled: PH is a constant in each copy of the body
     const int chunk = chunk0 + ph;
     const int PH = (ph * WGC) & 1;                       // parity of this chunk's first weight-group index
-    const char* const pb = smem + (chunk & 1) * PATCH_BYTES;
-    char* const pn = smem + ((chunk + 1) & 1) * PATCH_BYTES;
-    const bool more = chunk + 1 < nchunks;              // past the end the staging runs on zeros into the unused buffer (no branches
+    const char* const pb = smem + ((chunk - cb0) & 1) * PATCH_BYTES;
+    char* const pn = smem + ((chunk - cb0 + 1) & 1) * PATCH_BYTES;
+    const bool more = chunk + 1 < ce;                   // past the end the staging runs on zeros into the unused buffer (no branches
     const int cn = more ? chunk + 1 : chunk;            // around loads: the compiler then keeps exact vmcnt counts)
-    const bool more2 = chunk + 2 < nchunks;
+    const bool more2 = chunk + 2 < ce;
     const int cn2 = more2 ? chunk + 2 : chunk;
     const int gbase = chunk * WGC;
 #pragma unroll
@@ -294,6 +299,27 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
 
   CSTAMP(1);
   STAMP(2);
+  if constexpr (MF16 && !SPL && SK) {
+    {                        // raw partial sums: a lane holds 4 consecutive channels of a pixel (16 bytes fp32), quarter-waves complete 64-byte runs
+      float* const slab = (float*)a.ws + (int64_t)blockIdx.z * a.M * a.N;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const int n = n0 + wn * 32 + cb * 16 + 4 * (lane >> 4);
+        if (n < a.N) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+              const f32x4 c = acc4[i][sx][cb];
+              const int64_t m = ((int64_t)img * a.H + y0 + i) * a.W + x0 + sx * 16 + (lane & 15);
+              *(float4*)(slab + m * a.N + n) = make_float4(c[0], c[1], c[2], c[3]);
+            }
+        }
+      }
+      STAMP(3);
+      return;
+    }
+  }
   if constexpr (SPL) {
     // ---- precise-mode epilogue: straight from the accumulators.  A lane holds 4 consecutive channels of a pixel: 8 bytes of high parts
     // and 8 bytes of low parts, the four quarter-waves of a 16-channel block complete two 32-byte runs per pixel.  No statistics here
@@ -485,12 +511,15 @@ int launch_p(const pmi_igemm_args& a, hipStream_t s, int cfg) {
   }
   if (a.split_out) return PMI_ERR_ARG;
   if (cfg == 7) {                                      // 128-channel tiles, two 4-wave workgroups per CU
-    hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, true, 4, 32>), dim3(nimg * (a.H / 8) * (a.W / 32) * ((a.N + 127) / 128)), dim3(256), 0, s, a);
+    const int t7 = nimg * (a.H / 8) * (a.W / 32) * ((a.N + 127) / 128);
+    if (a.splitk > 1) hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, true, 4, 32, false, true>), dim3(t7, 1, a.splitk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, true, 4, 32>), dim3(t7), dim3(256), 0, s, a);
     PMI_CHECK_LAUNCH();
     return PMI_OK;
   }
   const int tiles = nimg * (a.H / 8) * (a.W / 32) * (a.N / 256);
-  if (cfg == 6) hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, true>), dim3(tiles), dim3(512), 0, s, a);    // v_mfma_f32_16x16x32
+  if (cfg == 6 && a.splitk > 1) hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, true, 8, 64, false, true>), dim3(tiles, 1, a.splitk), dim3(512), 0, s, a);
+  else if (cfg == 6) hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, true>), dim3(tiles), dim3(512), 0, s, a);    // v_mfma_f32_16x16x32
   else hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, false>), dim3(tiles), dim3(512), 0, s, a);             // config 4: 32x32x16
   PMI_CHECK_LAUNCH();
   return PMI_OK;
@@ -508,6 +537,26 @@ int launch_t(const pmi_igemm_args& a, hipStream_t s, int cfg) {
 }
 
 }  // namespace
+
+// Split-K factor for the weights-direct configs 6 / 7 (1 = none): output tiles alone leave most CUs idle on 32x32 maps at batch 8
+// (128 workgroups of 128 channels for a 512-channel layer); the reduction is split so that each part keeps >= 256 input channels.
+static int g_wd_splitk = 1;        // A/B switch: pmi_set_option(10, 0 / 1)
+void pmi_conv3x3_wd_splitk_enable(int v) { g_wd_splitk = v; }
+int pmi_conv3x3_wd_splitk(const pmi_igemm_args* a, int cfg) {
+  if (!g_wd_splitk || (cfg != 6 && cfg != 7) || a->split_out || a->split_in || a->out_f32 || (a->R && a->res_f32) || (a->N & 3)) return 1;
+  const int ck = cfg == 6 ? 64 : 32, bn = cfg == 6 ? 256 : 128;
+  const int nchunks = (a->C0 + a->C1) / ck;
+  const long wgs = (long)(a->M / (a->H * a->W)) * (a->H / 8) * (a->W / 32) * ((a->N + bn - 1) / bn);
+  if (wgs > 128) return 1;          // same-box A/B: 128 workgroups (512-channel layers, 32x32 x 8): c5 43.06 -> 42.82 ms; 160 (640 channels, c4): 15.32 -> 15.46, not split
+  int best = 1;
+  for (int s = 2; s <= 4; s *= 2) {
+    if (nchunks % s) continue;
+    const int per = nchunks / s;
+    if (per * ck < 256 || (cfg == 7 && (per & 1)) || wgs * s > 512) continue;
+    best = s;
+  }
+  return best;
+}
 
 int pmi_conv3x3_wd_launch(const pmi_igemm_args* a, int cfg, void* stream) {
   hipStream_t s = (hipStream_t)stream;

@@ -546,9 +546,13 @@ void pmi_conv3x3_prefer_256(int v);
 static int g_allow_halo = 1;
 // Split-K factor the generic kernel wants for this shape (1 = none): small-M layers (16x16 / 8x8 feature maps) otherwise
 // launch far fewer workgroups than the 256 CUs.  The caller then provides ws = S * M * N floats.
+int pmi_conv3x3_wd_splitk(const pmi_igemm_args* a, int cfg);        // conv_wd.hip
 extern "C" int pmi_igemm_splitk(const pmi_igemm_args* a) {
   if (a->batch > 1 || (a->N & 3)) return 1;
-  if (g_allow_halo && pmi_conv3x3_halo_config(a) >= 0) return 1;
+  if (g_allow_halo) {
+    const int halo = pmi_conv3x3_halo_config(a);
+    if (halo >= 0) return pmi_conv3x3_wd_splitk(a, halo);
+  }
   if (a->act == PMI_ACT_GEGLU) return 1;
   if (a->A1 && pmi_gemm_wd_eligible(a)) return 1;       // two-source weights-direct GEMM: no split-K
   if (pmi_gemm_wd_eligible(a)) {    // weights-direct GEMM: fill the 256 CUs with (row tile x 256-column) workgroups; >= 2 chunks of 128 per split
@@ -583,6 +587,7 @@ extern "C" int pmi_igemm_stats_rows(const pmi_igemm_args* a) {
 }
 
 void pmi_attn_flash_qt(int v);     // attn_flash.hip
+void pmi_conv3x3_wd_splitk_enable(int v);   // conv_wd.hip
 
 extern "C" int pmi_set_option(int key, int value) {
   if (key == 0) { const int old = g_allow_halo; g_allow_halo = value; return old; }
@@ -592,6 +597,7 @@ extern "C" int pmi_set_option(int key, int value) {
   if (key == 7) { pmi_conv3x3_wd_mf16(value); return 0; }
   if (key == 8) { pmi_conv3x3_wd128(value); return 0; }
   if (key == 9) { pmi_attn_flash_qt(value); return 0; }
+  if (key == 10) { pmi_conv3x3_wd_splitk_enable(value); return 0; }
   return PMI_ERR_ARG;
 }
 
@@ -624,7 +630,7 @@ extern "C" int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream) {
   const int halo = g_allow_halo ? pmi_conv3x3_halo_config(a) : -1;
   if (a->pro_a && (!a->pro_b || halo < 0)) return PMI_ERR_ARG;
   if (a->stats && a->stats_p != pmi_igemm_stats_rows(a)) return PMI_ERR_ARG;
-  if (a->splitk > 1 && (!a->ws || a->batch > 1 || halo >= 0 || (a->N & 3) || a->stats)) return PMI_ERR_ARG;
+  if (a->splitk > 1 && (!a->ws || a->batch > 1 || (halo >= 0 && a->splitk != pmi_conv3x3_wd_splitk(a, halo)) || (a->N & 3) || a->stats)) return PMI_ERR_ARG;
   if (a->act == PMI_ACT_GEGLU && !pmi_gemm_wd_eligible(a)) return bad_arg(__LINE__);     // the gated epilogue exists in the weights-direct GEMM only
   if (pmi_gemm_wd_eligible(a)) {
     const int rc = pmi_gemm_wd_launch(a, stream);
@@ -637,7 +643,17 @@ extern "C" int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream) {
     PMI_CHECK_LAUNCH();
     return PMI_OK;
   }
-  if (halo >= 4) return pmi_conv3x3_wd_launch(a, halo, stream);
+  if (halo >= 4) {
+    const int rc = pmi_conv3x3_wd_launch(a, halo, stream);
+    if (rc != PMI_OK || a->splitk <= 1) return rc;
+    hipStream_t s = (hipStream_t)stream;             // split-K: bias / per-sample bias / activation / residual in the reduce kernel
+    const int64_t work = (int64_t)a->M * (a->N / 4);
+    const int blocks = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
+    if (a->dtype == PMI_DT_BF16) hipLaunchKernelGGL(splitk_reduce_kernel<BF16>, dim3(blocks), dim3(256), 0, s, *a);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<F16>, dim3(blocks), dim3(256), 0, s, *a);
+    PMI_CHECK_LAUNCH();
+    return PMI_OK;
+  }
   if (halo >= 0) return pmi_conv3x3_halo_launch(a, halo, stream);
   hipStream_t s = (hipStream_t)stream;
   return a->dtype == PMI_DT_BF16 ? launch<BF16>(*a, s) : launch<F16>(*a, s);

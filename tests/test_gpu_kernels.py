@@ -78,6 +78,9 @@ def _check(got, ref, dtype, extra=1.0):
     dict(n=2, h=16, w=32, cin=192, cout=192, k=3, split=128, prologue=True, force_cfg=7),
     dict(n=1, h=16, w=64, cin=128, cout=448, k=3, res_up=True, prologue=True, force_cfg=7),
     dict(n=8, h=64, w=64, cin=320, cout=320, k=3, prologue=True),          # StableDiffusion level 0 (batch 8, 64x64 latents): picks the tail-tile config by itself
+    dict(n=8, h=32, w=32, cin=512, cout=512, k=3, prologue=True),          # 32x32 maps at batch 8: 128-channel tiles with split-K 2 (raw slabs + reduce)
+    dict(n=8, h=32, w=32, cin=1024, cout=512, k=3, split=512),             # split-K 4 over a two-source K
+    dict(n=8, h=32, w=32, cin=512, cout=512, k=3, res_up=True),            # the reduce kernel's up-sampled residual
     dict(n=8, h=64, w=64, cin=64, cout=256, k=3, prologue=True),           # enough tiles for the halo kernel by itself
     dict(n=8, h=128, w=64, cin=64, cout=6, k=3, f32=True, prologue=True),  # last conv of the UNet: halo config 3 (<= 32 output channels), fp32 out
     dict(n=8, h=128, w=64, cin=128, cout=24, k=3),                         # config 3, 16-bit out with a 16-bit residual
