@@ -21,7 +21,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from .. import _hip
-from .._hip import ACT_NONE, ACT_SILU, call, ptr
+from .._hip import ACT_SILU, call, ptr
 from . import ops
 from .ops import PackedLinear
 

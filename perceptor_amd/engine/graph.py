@@ -14,7 +14,7 @@ The returned tensor is the graph's static output buffer: clone it if it must sur
 """
 from __future__ import annotations
 
-from typing import Callable, Sequence
+from typing import Callable
 
 import torch
 

@@ -1,7 +1,6 @@
 """Launch wrappers for the fused sampler-update kernels (fp32 NCHW, per-sample scalars)."""
 from __future__ import annotations
 
-from typing import Optional
 
 import torch
 

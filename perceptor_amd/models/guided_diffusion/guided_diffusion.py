@@ -11,7 +11,7 @@ Differences that are deliberate and visible:
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Optional
 
 import numpy as np
 import torch

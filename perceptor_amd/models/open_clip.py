@@ -18,7 +18,6 @@ from typing import Optional
 
 import torch
 
-from .. import _hip
 from .._hip import call, ptr
 from ..engine import text as text_engine
 from ..engine import vit
