@@ -29,7 +29,7 @@
 #include "../../include/perceptor_hip.h"
 
 #ifndef WD_ILV
-#define WD_ILV 4     // VALU instructions of the patch staging the scheduler is asked to place behind each output row's MFMAs
+#define WD_ILV 2     // (4 until the last sweep: 2 leaves the 128-channel tiles 12 instead of 32 B/lane of scratch and measures +2 % there) VALU instructions of the patch staging the scheduler is asked to place behind each output row's MFMAs
 #endif
 
 namespace {
