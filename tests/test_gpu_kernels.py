@@ -367,3 +367,50 @@ def test_fused_output_statistics_feed_groupnorm(case, dtype):
     # statistics of the un-rounded fp32 outputs vs of the stored 16-bit tensor: differ by rounding noise only
     assert float((a_f - a_s).abs().max()) <= 4 * ULP[dtype] * float(a_s.abs().max())
     assert float((got - ref).abs().max()) <= 4 * ULP[dtype] * float(ref.abs().max())
+
+
+def test_gemm_routing_fuzz():
+    """Seeded sweep over the shape space the GEMM routing rules cut up (weights-direct 256- / 128-column tiles, N and K tails, two-source
+    K, split-K, generic kernel): whichever kernel a shape lands on, the result matches fp32 torch on pre-rounded operands."""
+    from perceptor_amd.engine import ops
+    from perceptor_amd._hip import dtype_code
+    import random
+    dev = _dev()
+    rnd = random.Random(11)
+    g = torch.Generator().manual_seed(12)
+    dtype = "bf16"
+    dt = dtype_code(dtype)
+    for it in range(28):
+        m = rnd.choice([64, 72, 200, 513, 1000, 2056, 4099])
+        n = 32 * rnd.randint(1, 40)
+        two = it % 3 == 0
+        k0 = 128 * rnd.randint(1, 6) if two else 32 * rnd.randint(1, 48)
+        k1 = 32 * rnd.randint(1, 12) if two else 0
+        k = k0 + k1
+        x = _r(torch.randn(m, k, generator=g), dtype)
+        wt = _r(torch.randn(n, k, generator=g) / k ** 0.5, dtype)
+        b = torch.randn(n, generator=g) * 0.1
+        res_kind = rnd.choice([None, "16", "f32"])
+        out_f32 = rnd.choice([False, True]) if res_kind != "16" else False
+        act = rnd.choice([0, 0, 2, 3])
+        ref = x @ wt.T + b
+        ref = F.silu(ref) if act == 2 else F.gelu(ref) if act == 3 else ref
+        res = None
+        if res_kind == "f32":
+            res = torch.randn(m, n, generator=g)
+            ref = ref + res
+            res = res.to(dev)
+        elif res_kind == "16":
+            res = _r(torch.randn(m, n, generator=g), dtype)
+            ref = ref + res
+            res = res.to(torch.bfloat16).to(dev)
+        lin = ops.PackedLinear(wt, b, dt, dev, sources=(k0, k1) if two else None)
+        xd = x.to(torch.bfloat16).to(dev)
+        a0, a1 = (xd[:, :k0].contiguous(), xd[:, k0:].contiguous()) if two else (xd, None)
+        out = ops.igemm(a0, lin, a1=a1, residual=res, act=act, out_f32=out_f32)
+        tag = (it, m, n, k0, k1, res_kind, out_f32, act)
+        if out_f32:
+            assert float((out.cpu() - ref).abs().max()) <= 3e-5 * (float(ref.abs().max()) + 1) * max(1.0, (k / 1024) ** 0.5) + 1e-6, tag
+        else:
+            d = (out.float().cpu() - ref).abs()
+            assert float(d.max()) <= 2.5 * ULP[dtype] * (float(ref.abs().max()) + 1e-6), tag
