@@ -283,3 +283,25 @@ def test_inpainting_checkpoint_surface_vs_oracle():
     init = m.latents(img)
     a600 = float(m.schedule_alphas[int(last.from_indices[0])])
     assert bool(keep.any()) and float(((last.from_diffused_latents - init * a600) * keep).abs().max()) < 6.0     # noise-level distance, finite
+
+
+def test_unet_and_vae_non_square_latents_vs_oracle():
+    """Latents whose width is not a multiple of 32 (24 x 40): the convolutions leave the 32-pixel-wide tile kernels for the generic one."""
+    from oracle import sd as osd
+    from perceptor_amd.engine import sd
+    from perceptor_amd.utils.synth import seeded_noise, synth_state_dict
+    cfg = sd.SdConfig(**osd.SD_MID.__dict__)
+    w = synth_state_dict(sd.unet_state_dict_shapes(cfg), 0)
+    x, ctx, t = seeded_noise((2, 4, 24, 40), 75), seeded_noise((2, 9, cfg.context_dim), 76), torch.tensor([700, 3])
+    with torch.no_grad():
+        want = osd.unet_forward(w, osd.SD_MID, x, t, ctx)
+    got = sd.SdUnetEngine(cfg, w, "cuda", "f16").forward(x.cuda(), t.cuda(), ctx.cuda()).cpu()
+    emax, el2 = _err(got, want)
+    assert emax < TOL["f16"][0] and el2 < TOL["f16"][1], (emax, el2)
+    vcfg = sd.VaeConfig(**osd.VAE_TINY.__dict__)
+    vw = synth_state_dict({**sd.vae_encoder_state_dict_shapes(vcfg), **sd.vae_decoder_state_dict_shapes(vcfg)}, 0)
+    z = seeded_noise((1, 4, 12, 20), 77)
+    with torch.no_grad():
+        img = (osd.vae_decode(vw, osd.VAE_TINY, z / 0.18215) + 1) / 2
+    out = sd.VaeDecoderEngine(vcfg, vw, "cuda", "bf16").forward(z.cuda()).cpu()
+    assert out.shape == (1, 3, 24, 40) and float((out - img).abs().max()) < 4e-2 * float((img - 0.5).abs().max())
