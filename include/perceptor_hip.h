@@ -252,6 +252,13 @@ int pmi_layernorm_fwd(const float* x, int ld_x, const float* gamma, const float*
 /* input gradient; dy row r (stride dy_ld) belongs to row r*row_stride of x/gres/outputs; out = dx + gres */
 int pmi_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean_rstd, const float* gres,
                       float* g32, void* g16, int M, int D, int dy_ld, int row_stride, int dtype, pmi_stream_t s);
+/* LayerNorm fused with the split-K reduction of the GEMM in front of it: the caller runs pmi_igemm with splitk > 1 and reserved3 = 1 (the
+ * slabs ws[splitk][M][D] are left unreduced) and passes them here.  forward: x = sum_s ws[s] + bias + residual -> x_out (fp32) and
+ * LayerNorm(x) as 16-bit operand (+ mean_rstd[2][M]); backward: dy = sum_s ws[s], then as pmi_layernorm_bwd.  D % 256 == 0, D <= 2048. */
+int pmi_layernorm_fwd_slabs(const float* ws, int nslab, int64_t slab_stride, const float* bias, const float* residual, float* x_out,
+                            const float* gamma, const float* beta, void* y16, float* mean_rstd, int M, int D, float eps, int dtype, pmi_stream_t s);
+int pmi_layernorm_bwd_slabs(const float* ws, int nslab, int64_t slab_stride, const float* x, const float* gamma, const float* mean_rstd,
+                            const float* gres, float* g32, void* g16, int M, int D, int dtype, pmi_stream_t s);
 /* softmax over the first T columns of fp32 scores * scale -> 16-bit probabilities (zero padded to ld_out) */
 int pmi_softmax_fwd(const float* S, void* P, int rows, int T, int ld_in, int ld_out, float scale, int dtype, pmi_stream_t s);
 /* CLIP text tower (open_clip text transformer reached through models/open_clip.py:99-107; transformers CLIPTextModel through

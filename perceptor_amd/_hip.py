@@ -114,6 +114,8 @@ _PROTOS = {
     # CLIP path (clip.hip)
     "pmi_layernorm_fwd": ([_P, _I, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],),
     "pmi_layernorm_bwd": ([_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],),
+    "pmi_layernorm_fwd_slabs": ([_P, _I, _L, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],),
+    "pmi_layernorm_bwd_slabs": ([_P, _I, _L, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],),
     "pmi_softmax_fwd": ([_P, _P, _I, _I, _I, _I, _F, _I, _P],),
     "pmi_softmax_causal_fwd": ([_P, _P, _I, _I, _I, _I, _F, _I, _P],),
     "pmi_embed_tokens": ([_P, _P, _P, _P, _I, _I, _I, _I, _P],),

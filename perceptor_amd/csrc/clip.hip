@@ -99,6 +99,101 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   }
 }
 
+// ---- LayerNorm fused with the split-K reduction of the GEMM in front of it (ViT, M = 2056: the reduce pass and the LayerNorm pass were two
+// launch-bound kernels over the same 8 MB).  x[row] = sum_s ws[s][row] + bias + residual[row]; one wave per row, the row stays in registers.
+// forward: writes x (the residual stream) and LayerNorm(x) as 16-bit GEMM operand (+ mean / rstd);  D % 256 == 0, D <= 2048.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_slabs_kernel(const float* __restrict__ ws, int nslab, int64_t slab_stride,
+                                                                  const float* __restrict__ bias, const float* __restrict__ res,
+                                                                  float* __restrict__ xo, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, u16* __restrict__ y16,
+                                                                  float* __restrict__ mean_o, float* __restrict__ rstd_o, int M, int D, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const int nv = D >> 8;
+  float4 v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < nv) {
+      const int c = (lane + 64 * k) * 4;
+      float4 a = *(const float4*)(ws + (int64_t)row * D + c);
+      for (int z = 1; z < nslab; ++z) {                       // fixed order: deterministic
+        const float4 p = *(const float4*)(ws + z * slab_stride + (int64_t)row * D + c);
+        a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+      }
+      if (bias) { const float4 b = *(const float4*)(bias + c); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+      if (res) { const float4 r = *(const float4*)(res + (int64_t)row * D + c); a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
+      *(float4*)(xo + (int64_t)row * D + c) = a;
+      v[k] = a;
+      s += a.x + a.y + a.z + a.w;
+    }
+  }
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < nv) {
+      const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
+      q += a * a + b * b + c * c + d * d;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / D + eps);
+  if (lane == 0 && mean_o) { mean_o[row] = mean; rstd_o[row] = rstd; }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < nv) {
+      const int c = (lane + 64 * k) * 4;
+      const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+      *(uint2*)(y16 + (int64_t)row * D + c) = pack4<T>((v[k].x - mean) * rstd * g.x + b.x, (v[k].y - mean) * rstd * g.y + b.y,
+                                                        (v[k].z - mean) * rstd * g.z + b.z, (v[k].w - mean) * rstd * g.w + b.w);
+    }
+  }
+}
+
+// backward: dy[row] = sum_s ws[s][row] (the input-gradient GEMM's split-K slabs), then layernorm_bwd_kernel's single-pass form
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_slabs_kernel(const float* __restrict__ ws, int nslab, int64_t slab_stride,
+                                                                  const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                                  const float* __restrict__ gres, float* __restrict__ g32,
+                                                                  u16* __restrict__ g16, int M, int D) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= M) return;
+  const float mean = mean_i[r], rstd = rstd_i[r];
+  const int nv = D >> 8;
+  float4 gy[8], xh[8];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < nv) {
+      const int c = (lane + 64 * k) * 4;
+      float4 d = *(const float4*)(ws + (int64_t)r * D + c);
+      for (int z = 1; z < nslab; ++z) {
+        const float4 p = *(const float4*)(ws + z * slab_stride + (int64_t)r * D + c);
+        d.x += p.x; d.y += p.y; d.z += p.z; d.w += p.w;
+      }
+      const float4 g = *(const float4*)(gamma + c), xv = *(const float4*)(x + (int64_t)r * D + c);
+      gy[k] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+      xh[k] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+      s1 += gy[k].x + gy[k].y + gy[k].z + gy[k].w;
+      s2 += gy[k].x * xh[k].x + gy[k].y * xh[k].y + gy[k].z * xh[k].z + gy[k].w * xh[k].w;
+    }
+  }
+  s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < nv) {
+      const int c = (lane + 64 * k) * 4;
+      float4 v = make_float4(rstd * (gy[k].x - s1 - xh[k].x * s2), rstd * (gy[k].y - s1 - xh[k].y * s2),
+                             rstd * (gy[k].z - s1 - xh[k].z * s2), rstd * (gy[k].w - s1 - xh[k].w * s2));
+      if (gres) { const float4 gr = *(const float4*)(gres + (int64_t)r * D + c); v.x += gr.x; v.y += gr.y; v.z += gr.z; v.w += gr.w; }
+      if (g32) *(float4*)(g32 + (int64_t)r * D + c) = v;
+      if (g16) *(uint2*)(g16 + (int64_t)r * D + c) = pack4<T>(v.x, v.y, v.z, v.w);
+    }
+  }
+}
+
 // ---- row softmax over the first T columns of fp32 scores; 16-bit probabilities, zero padding -----
 template <typename TT>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, u16* __restrict__ P, int rows, int T,
@@ -342,6 +437,24 @@ extern "C" int pmi_layernorm_bwd(const float* dy, const float* x, const float* g
   if (!dy || !x || !gamma || !mean_rstd || (!g32 && !g16) || M <= 0 || D <= 0) return PMI_ERR_ARG;
   dim3 grid((M + 3) / 4), block(256);
   BY_DTYPE(layernorm_bwd_kernel, dy, x, gamma, mean_rstd, mean_rstd + M, gres, g32, (u16*)g16, M, D, dy_ld, row_stride);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_layernorm_fwd_slabs(const float* ws, int nslab, int64_t slab_stride, const float* bias, const float* residual, float* x_out,
+                                       const float* gamma, const float* beta, void* y16, float* mean_rstd, int M, int D, float eps, int dtype,
+                                       pmi_stream_t s) {
+  if (!ws || !x_out || !gamma || !beta || !y16 || nslab < 1 || M <= 0 || D <= 0 || (D & 255) || D > 2048) return PMI_ERR_ARG;
+  dim3 grid((M + 3) / 4), block(256);
+  float* mo = mean_rstd; float* ro = mean_rstd ? mean_rstd + M : nullptr;
+  BY_DTYPE(layernorm_fwd_slabs_kernel, ws, nslab, slab_stride, bias, residual, x_out, gamma, beta, (u16*)y16, mo, ro, M, D, eps);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_layernorm_bwd_slabs(const float* ws, int nslab, int64_t slab_stride, const float* x, const float* gamma, const float* mean_rstd,
+                                       const float* gres, float* g32, void* g16, int M, int D, int dtype, pmi_stream_t s) {
+  if (!ws || !x || !gamma || !mean_rstd || (!g32 && !g16) || nslab < 1 || M <= 0 || D <= 0 || (D & 255) || D > 2048) return PMI_ERR_ARG;
+  dim3 grid((M + 3) / 4), block(256);
+  BY_DTYPE(layernorm_bwd_slabs_kernel, ws, nslab, slab_stride, x, gamma, mean_rstd, mean_rstd + M, gres, g32, (u16*)g16, M, D);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }

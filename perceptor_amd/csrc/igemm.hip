@@ -634,7 +634,7 @@ extern "C" int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream) {
   if (a->act == PMI_ACT_GEGLU && !pmi_gemm_wd_eligible(a)) return bad_arg(__LINE__);     // the gated epilogue exists in the weights-direct GEMM only
   if (pmi_gemm_wd_eligible(a)) {
     const int rc = pmi_gemm_wd_launch(a, stream);
-    if (rc != PMI_OK || a->splitk <= 1) return rc;
+    if (rc != PMI_OK || a->splitk <= 1 || a->reserved3 == 1) return rc;      // reserved3 = 1: the caller consumes the raw slabs (fused reduce + LayerNorm)
     hipStream_t s = (hipStream_t)stream;             // split-K: the slabs get bias / activation / residual in the reduce kernel
     const int64_t work = (int64_t)a->M * (a->N / 4);
     const int blocks = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);

@@ -153,7 +153,7 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
           act: int = ACT_NONE, up: bool = False, stride: int = 1, res_up: bool = False, nbias: Optional[torch.Tensor] = None,
           out_f32: bool = False, out: Optional[torch.Tensor] = None, alpha: float = 1.0, prologue=None,
           want_stats: bool = False, hw: Optional[int] = None, pre_out: Optional[torch.Tensor] = None,
-          act_grad_of: Optional[torch.Tensor] = None, act_grad: int = ACT_NONE) -> torch.Tensor:
+          act_grad_of: Optional[torch.Tensor] = None, act_grad: int = ACT_NONE, defer_reduce: bool = False) -> torch.Tensor:
     """Convolution (a0 is [N,H,W,C]) or linear (a0 is [M,C]) through pmi_igemm.
 
     prologue = (coef_a [N,Cin], coef_b [N,Cin], act): fused GroupNorm-apply(+FiLM)+activation on the conv input
@@ -231,6 +231,11 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
         if sk > 1:   # few output tiles, long K: split the reduction over grid.z into fp32 slabs
             ws = _empty((sk, m, lin.n_p), torch.float32, a0.device)
             a.ws, a.splitk = ptr(ws), sk
+            if defer_reduce and a.Bf and not conv and _hip.lib().pmi_gemm_wd_eligible(C.byref(a)):
+                # the caller fuses the reduction (+ bias / residual) into its next pass (LayerNorm): leave the raw slabs
+                a.reserved3 = 1
+                call("pmi_igemm", C.byref(a))
+                return ("slabs", ws, sk)
     if want_stats:
         rows = _hip.lib().pmi_igemm_stats_rows(C.byref(a))
         if rows > 0:   # fused per-channel (sum, sumsq) of the output for the next GroupNorm

@@ -154,6 +154,27 @@ class VitEngine:
         call("pmi_layernorm_bwd", ptr(dy), ptr(x), ptr(gb[0]), ptr(mr), ptr(gres), ptr(g32), ptr(g16), m, d, dy_ld, row_stride, self.dt)
         return g32, g16
 
+    def _ln_slabs(self, slabs, bias, residual, gb, m, d):
+        """x = sum of the GEMM's split-K slabs + bias + residual (the residual stream, fp32) and LayerNorm(x) as the next GEMM's operand,
+        one pass (pmi_layernorm_fwd_slabs)."""
+        _, ws, sk = slabs
+        dev = ws.device
+        x = torch.empty((m, d), dtype=torch.float32, device=dev)
+        y16 = torch.empty((m, d), dtype=_hip.TORCH_DTYPE[self.dt], device=dev)
+        mr = torch.empty((2, m), dtype=torch.float32, device=dev)
+        call("pmi_layernorm_fwd_slabs", ptr(ws), sk, m * d, ptr(bias), ptr(residual), ptr(x), ptr(gb[0]), ptr(gb[1]), ptr(y16), ptr(mr), m, d, 1e-5, self.dt)
+        return x, y16, mr
+
+    def _ln_bwd_any(self, dy, x, gb, mr, gres, m, d):
+        """LayerNorm input gradient from the input-gradient GEMM's output -- or straight from its unreduced split-K slabs."""
+        if isinstance(dy, tuple):
+            _, ws, sk = dy
+            g32 = torch.empty((m, d), dtype=torch.float32, device=x.device)
+            g16 = torch.empty((m, d), dtype=_hip.TORCH_DTYPE[self.dt], device=x.device)
+            call("pmi_layernorm_bwd_slabs", ptr(ws), sk, m * d, ptr(x), ptr(gb[0]), ptr(mr), ptr(gres), ptr(g32), ptr(g16), m, d, self.dt)
+            return g32, g16
+        return self._ln_bwd(dy, d, x, gb, mr, gres, m, d)
+
     def _transpose(self, src: torch.Tensor, off: int, rows: int, cols: int, ld: int, s_o: int, s_i: int, inner: int, batch: int):
         rp = (rows + 7) // 8 * 8
         out = torch.empty((batch, cols, rp), dtype=src.dtype, device=src.device)
@@ -185,8 +206,14 @@ class VitEngine:
         _, x, mr_pre = self._ln(x0, width, self.ln_pre, m, width, want16=False, want32=True)
         sv = dict(in_hw=tuple(images.shape[2:]), n=n, x0=x0, mr_pre=mr_pre, layers=[]) if save else None
         scale = float(d) ** -0.5
-        for blk in self.blocks:
-            h, _, mr1 = self._ln(x, width, blk["ln1"], m, width)
+        fuse = width % 256 == 0 and width <= 2048            # split-K reduce of the MLP's last GEMM + the next block's LayerNorm in one pass
+        nxt = None                                           # (h, mr1) of this block when the previous block's tail already produced them
+        for bi, blk in enumerate(self.blocks):
+            if nxt is None:
+                h, _, mr1 = self._ln(x, width, blk["ln1"], m, width)
+            else:
+                h, mr1 = nxt
+                nxt = None
             qkv = ops.igemm(h, blk["qkv"].fwd)                                    # [m, 3*width], (q|k|v) x (head, d)
             a = torch.empty((m, width), dtype=tdt, device=dev)
             fused = d == 64
@@ -215,7 +242,11 @@ class VitEngine:
                 hpre = ops.igemm(h2, blk["fc"].fwd)
                 hact = torch.empty_like(hpre)
                 call("pmi_act_fwd", ptr(hpre), ptr(hact), hpre.numel(), self.act, dt)
-            x_out = ops.igemm(hact, blk["pr"].fwd, residual=x_mid, out_f32=True)
+            last = bi + 1 == len(self.blocks)
+            x_out = ops.igemm(hact, blk["pr"].fwd, residual=x_mid, out_f32=True, defer_reduce=fuse and not last)
+            if isinstance(x_out, tuple):
+                x_out, hn, mrn = self._ln_slabs(x_out, blk["pr"].fwd.b, x_mid, self.blocks[bi + 1]["ln1"], m, width)
+                nxt = (hn, mrn)
             if save:
                 sv["layers"].append(dict(x_in=x, mr1=mr1, qkv=qkv if not fused else None, p=p, aws=aws, lse=lse, a=a if fused else None,
                                          x_mid=x_mid, mr2=mr2, hpre=hpre))
@@ -259,8 +290,9 @@ class VitEngine:
             else:
                 dh = ops.igemm(g16, blk["pr"].bwd)
                 call("pmi_act_bwd", ptr(dh), ptr(L["hpre"]), ptr(dh), dh.numel(), self.act, dt)
-            dln2 = ops.igemm(dh, blk["fc"].bwd, out_f32=True)
-            gm32, gm16 = self._ln_bwd(dln2, width, L["x_mid"], blk["ln2"], L["mr2"], g32, m, width)
+            fuse = width % 256 == 0 and width <= 2048
+            dln2 = ops.igemm(dh, blk["fc"].bwd, out_f32=True, defer_reduce=fuse)
+            gm32, gm16 = self._ln_bwd_any(dln2, L["x_mid"], blk["ln2"], L["mr2"], g32, m, width)
             # ---- attention branch
             da = ops.igemm(gm16, blk["out"].bwd)                                    # dO, [m, w] (head, d)
             w3 = 3 * width
@@ -289,8 +321,8 @@ class VitEngine:
                 qt = self._transpose(qkv, 0, t, d, w3, t * w3, d, heads, n * heads)
                 ops.bgemm(dst, qt, dqkv, M=t, N=d, K=tp, lda=tp, ldb=tp, ldd=w3, batch=n * heads, batch_inner=heads,
                           sA=(heads * t * tp, t * tp), sB=(heads * d * tp, d * tp), sD=(t * w3, d), dt=dt, d_off=width)       # dK
-            dln1 = ops.igemm(dqkv, blk["qkv"].bwd, out_f32=True)
-            g32, g16 = self._ln_bwd(dln1, width, L["x_in"], blk["ln1"], L["mr1"], gm32, m, width)
+            dln1 = ops.igemm(dqkv, blk["qkv"].bwd, out_f32=True, defer_reduce=fuse)
+            g32, g16 = self._ln_bwd_any(dln1, L["x_in"], blk["ln1"], L["mr1"], gm32, m, width)
         _, g0 = self._ln_bwd(g32, width, sv["x0"], self.ln_pre, sv["mr_pre"], None, m, width, want32=False)
         dcol = torch.empty((n * (t - 1), self.kp), dtype=torch.float32, device=dev)
         ops.bgemm(g0, self.conv1.bwd.w, dcol, M=t - 1, N=self.kp, K=width, lda=width, ldb=width, ldd=self.kp, batch=n, batch_inner=1,
