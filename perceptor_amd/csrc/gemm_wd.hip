@@ -295,7 +295,8 @@ int launch(const pmi_igemm_args& a, hipStream_t s, int mb) {
   const int tm = 16 * mb;
   // fewer than 128 workgroups of 256 columns and no split-K (short K): the 128-column tiles double the grid (2056 x 1024 x 1024: 14.2 vs 16.7 us)
   const bool few = a.splitk <= 1 && (long)((a.M + 127) / 128) * ((a.N + 255) / 256) < 128 && !a.D2 && !a.aux && a.act != PMI_ACT_GEGLU;
-  if (a.N < 256 || few) {                              // 128-column tiles, four waves, two workgroups per CU
+  const bool half_tail = (a.N % 256) != 0 && (a.N % 256) <= 128 && a.N < 1024;     // e.g. N = 320: 3 tiles of 128 instead of 2 of 256 (one a quarter full)
+  if (a.N < 256 || few || half_tail) {                 // 128-column tiles, four waves, two workgroups per CU
     const dim3 g4(((a.M + 127) / 128) * ((a.N + 127) / 128), 1, a.splitk > 1 ? a.splitk : 1);
     if (a.A1) hipLaunchKernelGGL((gemm_wd_kernel<T, 8, true, 4>), g4, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gemm_wd_kernel<T, 8, false, 4>), g4, dim3(256), 0, s, a);
@@ -314,7 +315,7 @@ int launch(const pmi_igemm_args& a, hipStream_t s, int mb) {
 
 // rows per tile (128 or 144): fewest rounds of 256 workgroups, then least work per workgroup
 int pmi_gemm_wd_tile_rows(const pmi_igemm_args* a, int splitk) {
-  if (a->A1 || a->N < 256) return 128;
+  if (a->A1 || a->N < 256 || ((a->N % 256) != 0 && (a->N % 256) <= 128 && a->N < 1024)) return 128;
   if (splitk <= 1 && (long)((a->M + 127) / 128) * ((a->N + 255) / 256) < 128 && !a->D2 && !a->aux && a->act != PMI_ACT_GEGLU) return 128;
   int best = 8;
   long best_cost = -1;
@@ -335,7 +336,7 @@ extern "C" int pmi_gemm_wd_eligible(const pmi_igemm_args* a) {
   if (a->N < 256 && a->N != 128) return 0;  // N = 128: the four-wave 128-column tiles; other narrow matrices stay on the generic kernel
   if ((a->N % 256) && a->N < 1024) {        // narrow matrix with a partly filled last tile: measured per shape against the generic 128-wide tiles (tools/sd_trace.py)
     const int tail = a->N % 256;
-    if (tail < 64 || (tail < 128 && a->R && a->res_f32)) return 0;      // (N = 320 with an fp32 residual: 50 vs 45 us; without: 26 vs 29, fp32 out 34 vs 42)
+    if (tail < 64) return 0;      // (N = 320 runs on the 128-column tiles: see launch())
   }
   if ((a->D2 || a->aux) && (a->out_f32 || a->splitk > 1 || (a->R && a->res_f32))) return 0;
   if (a->act == PMI_ACT_GEGLU && (a->R || a->D2 || a->aux || a->out_f32 || a->splitk > 1)) return 0;
