@@ -99,3 +99,25 @@ def test_transformers_openai_clip_surface_vs_clipmodel_fixture():
     assert float(cos) > 0.999 and _rel(img.grad.cpu(), g["grad"]) < 3e-2
     with pytest.raises(NotImplementedError):
         models.TransformersOpenAICLIP("M-CLIP/XLM-Roberta-Large-Vit-L-14")
+
+
+def test_loss_add_texts_end_to_end():
+    """losses.OpenCLIP.add_texts_ (losses/open_clip.py:60-66 -> models.OpenCLIP.encode_texts) feeding the image loss: text prompts through the
+    tokenizer and the HIP text tower become the targets of the spherical loss, whose gradient reaches the images."""
+    from perceptor_amd import losses
+    from perceptor_amd.utils.synth import seeded_noise
+    from perceptor_amd.utils.tokenizer import ClipTokenizer
+    loss = losses.OpenCLIP("tiny", "synthetic", quick_gelu=True, config=TINY_VIT, text_config=(16, 520, 64, 2, 1, 32)).to("cuda")
+    loss.model._tokenizer = ClipTokenizer(merges=[("a", "b"), ("ab", "c</w>"), ("c", "a")])
+    loss.add_texts_(["abc cab", "b"], weights=[1.0, 0.5])
+    assert loss.encodings.shape == (2, 32) and float((loss.encodings.norm(dim=1) - 1).abs().max()) < 1e-5
+    want = loss.model.encode_texts(["abc cab", "b"])
+    assert torch.equal(loss.encodings.data, want)
+    img = (seeded_noise((2, 3, 40, 40), 52) * 0.25 + 0.5).cuda()
+    val, grad = loss.loss_and_grad(img)
+    assert bool(torch.isfinite(val)) and grad.shape == img.shape and float(grad.abs().max()) > 0
+    x = img.clone().requires_grad_(True)
+    with torch.enable_grad():
+        loss(x).backward()
+    cos = torch.nn.functional.cosine_similarity(x.grad.flatten(), grad.flatten(), dim=0)
+    assert float(cos) > 0.9999
