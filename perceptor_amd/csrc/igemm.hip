@@ -544,6 +544,7 @@ void pmi_conv3x3_wd128(int v);
 void pmi_conv3x3_force_config(int cfg);
 void pmi_conv3x3_prefer_256(int v);
 static int g_allow_halo = 1;
+static int g_wd_max_split = 8;      // A/B switch: pmi_set_option(11, n)
 // Split-K factor the generic kernel wants for this shape (1 = none): small-M layers (16x16 / 8x8 feature maps) otherwise
 // launch far fewer workgroups than the 256 CUs.  The caller then provides ws = S * M * N floats.
 int pmi_conv3x3_wd_splitk(const pmi_igemm_args* a, int cfg);        // conv_wd.hip
@@ -559,7 +560,7 @@ extern "C" int pmi_igemm_splitk(const pmi_igemm_args* a) {
     const int nch = (a->K + 127) / 128;
     int best = 1;
     long best_cost = -1;
-    for (int s = 1; s <= 8 && nch / s >= 4; s *= 2) {
+    for (int s = 1; s <= g_wd_max_split && nch / s >= 4; s *= 2) {
       const int rows = pmi_gemm_wd_tile_rows(a, s);
       const long wgs = (long)((a->M + rows - 1) / rows) * (a->N < 256 ? 1 : (a->N + 255) / 256) * s;
       // rounds x rows x (chunks + fixed prologue / epilogue share); a split pays for its fp32 slabs and the reduce launch
@@ -598,6 +599,7 @@ extern "C" int pmi_set_option(int key, int value) {
   if (key == 8) { pmi_conv3x3_wd128(value); return 0; }
   if (key == 9) { pmi_attn_flash_qt(value); return 0; }
   if (key == 10) { pmi_conv3x3_wd_splitk_enable(value); return 0; }
+  if (key == 11) { g_wd_max_split = value; return 0; }
   return PMI_ERR_ARG;
 }
 
