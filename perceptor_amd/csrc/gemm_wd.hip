@@ -290,11 +290,13 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_wd_kernel(const pmi_igemm_ar
   GSTAMP(3);
 }
 
+static int g_few_wgs = 128;        // A/B switch: pmi_set_option(12, n): 256-column grids below n workgroups use the 128-column tiles
+
 template <typename T>
 int launch(const pmi_igemm_args& a, hipStream_t s, int mb) {
   const int tm = 16 * mb;
   // fewer than 128 workgroups of 256 columns and no split-K (short K): the 128-column tiles double the grid (2056 x 1024 x 1024: 14.2 vs 16.7 us)
-  const bool few = a.splitk <= 1 && (long)((a.M + 127) / 128) * ((a.N + 255) / 256) < 128 && !a.D2 && !a.aux && a.act != PMI_ACT_GEGLU;
+  const bool few = a.splitk <= 1 && (long)((a.M + 127) / 128) * ((a.N + 255) / 256) < g_few_wgs && !a.D2 && !a.aux && a.act != PMI_ACT_GEGLU;
   const bool half_tail = (a.N % 256) != 0 && (a.N % 256) <= 128 && a.N < 1024;     // e.g. N = 320: 3 tiles of 128 instead of 2 of 256 (one a quarter full)
   if (a.N < 256 || few || half_tail) {                 // 128-column tiles, four waves, two workgroups per CU
     const dim3 g4(((a.M + 127) / 128) * ((a.N + 127) / 128), 1, a.splitk > 1 ? a.splitk : 1);
@@ -313,10 +315,12 @@ int launch(const pmi_igemm_args& a, hipStream_t s, int mb) {
 
 }  // namespace
 
+void pmi_gemm_wd_few_wgs(int v) { g_few_wgs = v; }
+
 // rows per tile (128 or 144): fewest rounds of 256 workgroups, then least work per workgroup
 int pmi_gemm_wd_tile_rows(const pmi_igemm_args* a, int splitk) {
   if (a->A1 || a->N < 256 || ((a->N % 256) != 0 && (a->N % 256) <= 128 && a->N < 1024)) return 128;
-  if (splitk <= 1 && (long)((a->M + 127) / 128) * ((a->N + 255) / 256) < 128 && !a->D2 && !a->aux && a->act != PMI_ACT_GEGLU) return 128;
+  if (splitk <= 1 && (long)((a->M + 127) / 128) * ((a->N + 255) / 256) < g_few_wgs && !a->D2 && !a->aux && a->act != PMI_ACT_GEGLU) return 128;
   int best = 8;
   long best_cost = -1;
   for (int mb = 8; mb <= 9; ++mb) {
