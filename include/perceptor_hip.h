@@ -95,7 +95,8 @@ int pmi_igemm_stats_rows(const pmi_igemm_args* a);
  * key 1 = force halo tile config 0/1/2 where eligible (-1 = automatic);
  * key 2 = prefer the 8-wave 256-channel halo config over two 4-wave workgroups per CU where the grid allows (default 1);
  * key 6 = allow the weights-direct conv3x3 kernel (default 1); key 7 = its 16x16x32-MFMA form, tile config 6, instead of config 4 (default 1);
- * key 8 = allow its 128-channel form, tile config 7 (4 waves, two workgroups per CU), for Cout % 256 != 0 (default 1).
+ * key 8 = allow its 128-channel form, tile config 7 (4 waves, two workgroups per CU), for Cout % 256 != 0 (default 1);
+ * key 13 = allow its first-convolution form, tile config 8 (at most 32 input channels, the whole K in registers) (default 1).
  * The library links no vendor GEMM / BLAS: every kernel it launches is in csrc/. */
 int pmi_set_option(int key, int value);
 

@@ -421,6 +421,8 @@ static int g_wd_mf16 = 1;      // pmi_set_option(7, v): its v_mfma_f32_16x16x32 
 void pmi_conv3x3_allow_wd(int v) { g_wd = v; }
 void pmi_conv3x3_wd_mf16(int v) { g_wd_mf16 = v; }
 void pmi_conv3x3_wd128(int v) { g_wd128 = v; }
+static int g_wd_smallc = 1;    // pmi_set_option(13, v): allow config 8 (at most 32 input channels)
+void pmi_conv3x3_wd_smallc(int v) { g_wd_smallc = v; }
 void pmi_conv3x3_force_config(int cfg) { g_force_cfg = cfg; }
 void pmi_conv3x3_prefer_256(int v) { g_prefer0 = v; }
 
@@ -429,6 +431,11 @@ void pmi_conv3x3_prefer_256(int v) { g_prefer0 = v; }
 extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
   if (a->taps != 9 || a->stride != 1 || a->batch > 1) return -1;
   const int Cin = a->C0 + a->C1;
+  // config 8: at most 32 input channels (the first convolution of the UNets): weights-direct tile with the whole K in registers
+  if (a->Bf && g_wd && g_wd_mf16 && g_wd_smallc && a->C1 == 0 && !a->A1 && a->C0 <= 32 && (a->C0 % 8) == 0 && !a->up && (a->W % 32) == 0 && (a->H % 8) == 0 && !a->pro_a &&
+      !a->split_out && !a->split_in && !a->out_f32 && !(a->R && a->res_f32) && (a->N % 32) == 0 && a->N >= 64 && (g_force_cfg < 0 || g_force_cfg == 8) &&
+      (long)(a->M / (a->H * a->W)) * (a->H / 8) * (a->W / 32) * ((a->N + 127) / 128) >= (g_force_cfg == 8 ? 1 : 256))
+    return 8;
   if ((Cin % 64) || (a->C0 % 64) || (a->W % 32) || (a->H % 8)) return -1;
   if (a->split_out || a->split_in) {
     // precise mode (hi + lo f16 pairs): the weights-direct kernel's 16x16x32 configs only -- its input is an ordinary K dimension of 2C

@@ -43,7 +43,10 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // SPL: precise mode (dtype 2): the output (and a residual) are hi + lo f16 pairs, [C/32][hi 32 | lo 32] per pixel (common.h: F16X2); the
 // input needs nothing special -- its 2C physical channels are an ordinary K dimension against duplicated weights.
 // SK: split-K over grid.z (its own instantiation: the chunk-range variables cost the unsplit kernel registers it does not have)
-template <typename T, int PRO, bool MF16, int NWN = 8, int CK = 64, bool SPL = false, bool SK = false>
+// SMALLC (config 8): at most 32 input channels (the UNets' first convolution: 3 image channels padded to 8, SD's 4 latent channels, yfcc's 19 -> 24):
+// the whole K = 9 taps x Cin fits a handful of 32-deep MFMA steps, so the patch (10 x 34 pixels x Cin) is staged once, the wave's weights sit in
+// registers, and the B fragments are gathered per tap straight from the patch; tile, accumulator layout and epilogue are config 7's.
+template <typename T, int PRO, bool MF16, int NWN = 8, int CK = 64, bool SPL = false, bool SK = false, bool SMALLC = false>
 __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm_args a) {
   constexpr int NW = NWN, NT = NW * 64;
   constexpr int KS = MF16 ? CK / 32 : CK / 16;         // k-steps (one MFMA deep) per chunk
@@ -164,6 +167,55 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc4[i][(r >> 3) & 1][(r >> 2) & 1][r & 3] = 0.f;
 
+  if constexpr (SMALLC) {
+    static_assert(MF16 && NWN == 4 && PRO == 0 && !SPL && !SK, "config 8 is a 128-channel-tile instantiation");
+    const int Cp = a.C0, C8 = Cp >> 3;                     // 8 .. 32 input channels, one source
+    const int KSS = (9 * Cp + 31) >> 5;                    // 32-deep MFMA steps over k = tap * Cp + c (3 .. 9); weights are zero past 9 * Cp
+    const u16* const Ai = (const u16*)a.A0 + (int64_t)img * a.Hin * a.Win * a.lda0;
+    for (int p = tid; p < PP * C8; p += NT) {              // the patch, [pixel][Cp] 16-bit, zero outside the image
+      const int pp = p / C8, c8 = p - pp * C8;
+      const int py = pp / PW, px = pp - py * PW;
+      const int sy = y0 - 1 + py, sx = x0 - 1 + px;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if ((unsigned)sy < (unsigned)a.H && (unsigned)sx < (unsigned)a.W) v = *(const uint4*)(Ai + ((int64_t)sy * a.W + sx) * a.lda0 + c8 * 8);
+      *(uint4*)(smem + (pp * Cp + c8 * 8) * 2) = v;
+    }
+    // this wave's weights, host-packed (PackedLinear.frag_c8): [N/32][KSS][16-channel block (2)][lane][8]
+    uint4 wsm[9][2];
+    int boff[9];                                           // byte offset of the lane's 8 input channels of step s inside the patch, relative to its pixel
+    const bool wave_ok = n0 + wn * 32 < a.N;
+    const char* const wb = (const char*)a.Bf + (int64_t)(tn * NWN + wn) * KSS * 2048 + lane * 16;
+#pragma unroll
+    for (int s_ = 0; s_ < 9; ++s_) {
+      wsm[s_][0] = wsm[s_][1] = make_uint4(0, 0, 0, 0);
+      boff[s_] = 0;
+      if (s_ < KSS) {
+        if (wave_ok) { wsm[s_][0] = *(const uint4*)(wb + s_ * 2048); wsm[s_][1] = *(const uint4*)(wb + s_ * 2048 + 1024); }
+        const int k0 = 32 * s_ + 8 * (lane >> 4);
+        int tap = k0 / Cp;
+        const int c0 = k0 - tap * Cp;
+        tap = tap > 8 ? 8 : tap;                           // past the last tap the weights are zero: any valid address
+        boff[s_] = (((tap / 3) * PW + (tap % 3)) * Cp + c0) * 2;
+      }
+    }
+    __syncthreads();
+    const int pix0 = (lane & 15) * Cp * 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int sx = 0; sx < 2; ++sx) {
+        const char* const pb_ = smem + pix0 + ((i * PW + sx * 16) * Cp) * 2;
+#pragma unroll
+        for (int s_ = 0; s_ < 9; ++s_) {
+          if (s_ < KSS) {
+            const uint4 bf = *(const uint4*)(pb_ + boff[s_]);
+            acc4[i][sx][0] = T::mfma16(wsm[s_][0], bf, acc4[i][sx][0]);
+            acc4[i][sx][1] = T::mfma16(wsm[s_][1], bf, acc4[i][sx][1]);
+          }
+        }
+      }
+    __syncthreads();                                       // every wave is done with the patch before the epilogue reuses the LDS
+  } else {
   uint4 wq[MF16 ? 2 : 3][NWF];                          // [ring slot][dy (x channel block)]
   auto load_wg = [&](int slot, int group) {             // groups past the end fall outside the resource: zeros (the range check
     const uint32_t vo = wvo + (uint32_t)group * (uint32_t)GB;   // covers the vector offset, so the group offset goes there)
@@ -297,6 +349,7 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
    }
   }
 
+  }
   CSTAMP(1);
   STAMP(2);
   if constexpr (MF16 && !SPL && SK) {
@@ -510,6 +563,14 @@ int launch_p(const pmi_igemm_args& a, hipStream_t s, int cfg) {
     }
   }
   if (a.split_out) return PMI_ERR_ARG;
+  if (cfg == 8) {                                      // at most 32 input channels (first convolution): PRO == 0 only
+    if constexpr (PRO == 0) {
+      hipLaunchKernelGGL((conv3x3_wd_kernel<T, 0, true, 4, 32, false, false, true>), dim3(nimg * (a.H / 8) * (a.W / 32) * ((a.N + 127) / 128)), dim3(256), 0, s, a);
+      PMI_CHECK_LAUNCH();
+      return PMI_OK;
+    }
+    return PMI_ERR_ARG;
+  }
   if (cfg == 7) {                                      // 128-channel tiles, two 4-wave workgroups per CU
     const int t7 = nimg * (a.H / 8) * (a.W / 32) * ((a.N + 127) / 128);
     if (a.splitk > 1) hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, true, 4, 32, false, true>), dim3(t7, 1, a.splitk), dim3(256), 0, s, a);

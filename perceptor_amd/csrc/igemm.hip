@@ -590,6 +590,7 @@ extern "C" int pmi_igemm_stats_rows(const pmi_igemm_args* a) {
 void pmi_attn_flash_qt(int v);     // attn_flash.hip
 void pmi_conv3x3_wd_splitk_enable(int v);   // conv_wd.hip
 void pmi_gemm_wd_few_wgs(int v);            // gemm_wd.hip
+void pmi_conv3x3_wd_smallc(int v);          // conv3x3.hip
 
 extern "C" int pmi_set_option(int key, int value) {
   if (key == 0) { const int old = g_allow_halo; g_allow_halo = value; return old; }
@@ -602,6 +603,7 @@ extern "C" int pmi_set_option(int key, int value) {
   if (key == 10) { pmi_conv3x3_wd_splitk_enable(value); return 0; }
   if (key == 11) { g_wd_max_split = value; return 0; }
   if (key == 12) { pmi_gemm_wd_few_wgs(value); return 0; }
+  if (key == 13) { pmi_conv3x3_wd_smallc(value); return 0; }
   return PMI_ERR_ARG;
 }
 

@@ -138,6 +138,18 @@ class PackedLinear:
             self._frag[key] = w.permute(0, 5, 4, 6, 3, 1, 7, 2, 8).contiguous()
         return self._frag[key]
 
+    def frag_c8(self) -> torch.Tensor:
+        """Fragment order for config 8 of the weights-direct kernel (at most 32 input channels): k = tap * Cin + c zero-padded to whole
+        32-deep MFMA steps, [N/32][steps][16-channel block (2)][lane = 16*(k quarter) + channel][8 k]."""
+        if "c8" not in self._frag:
+            assert self.taps == 9 and self.n_p % 32 == 0 and self.cin_p % 8 == 0 and self.cin_p <= 32
+            ks = (9 * self.cin_p + 31) // 32
+            w = torch.zeros((self.n_p, ks * 32), dtype=self.w.dtype, device=self.w.device)
+            w[:, :self.K] = self.w
+            w = w.view(self.n_p // 32, 2, 16, ks, 4, 8)                       # nb, cb, r16, step, q4, j
+            self._frag["c8"] = w.permute(0, 3, 1, 4, 2, 5).contiguous()
+        return self._frag["c8"]
+
     def frag(self, ck: int) -> torch.Tensor:
         """The 3x3 weights in MFMA fragment order for the weights-direct kernel (csrc/conv_wd.hip):
         [N/32][Cin/ck][dx][ck/16][dy][lane = 32*(k half) + channel][8 k] -- every (n-block, chunk, dx, k-step, dy)
@@ -200,12 +212,12 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
     a.ldnb = nbias.stride(0) if nbias is not None else 0
     a.batch, a.batch_inner = 1, 1
     a.dtype = dt
-    if conv and lin.taps == 9 and stride == 1 and HALO_ENABLED and WD_ENABLED and lin.n_p % 32 == 0 and lin.n_p >= 128 and lin.cin_p % 64 == 0:
+    if conv and lin.taps == 9 and stride == 1 and HALO_ENABLED and WD_ENABLED and lin.n_p % 32 == 0 and ((lin.n_p >= 128 and lin.cin_p % 64 == 0) or (lin.cin_p <= 32 and a1 is None and not lin.split)):
         a.Bf = 1                       # ask which tile config the weights-direct kernel would run, then hand it that packing
         a.pro_a = 1 if (prologue is not None and not lin.split) else None     # (the table size limit depends on a fused prologue)
         cfg = _hip.lib().pmi_conv3x3_halo_config(C.byref(a))
         a.pro_a = None
-        a.Bf = ptr(lin.frag16(64)) if cfg == 6 else ptr(lin.frag16(32)) if cfg == 7 else ptr(lin.frag(64)) if cfg == 4 else None
+        a.Bf = ptr(lin.frag16(64)) if cfg == 6 else ptr(lin.frag16(32)) if cfg == 7 else ptr(lin.frag(64)) if cfg == 4 else ptr(lin.frag_c8()) if cfg == 8 else None
     if pre_out is not None or act_grad_of is not None:
         a.D2, a.aux, a.aux_act = ptr(pre_out), ptr(act_grad_of), act_grad
     if GEMM_WD_ENABLED and lin.taps == 1 and not lin.split and not up and stride == 1 and lin.n_p % 32 == 0 and lin.K % 32 == 0 \

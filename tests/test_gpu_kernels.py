@@ -77,6 +77,11 @@ def _check(got, ref, dtype, extra=1.0):
     dict(n=1, h=8, w=64, cin=128, cout=320, k=3, force_cfg=7),             # config 7 with a Cout tail: 320 = 2.5 tiles, two dead waves in the last one
     dict(n=2, h=16, w=32, cin=192, cout=192, k=3, split=128, prologue=True, force_cfg=7),
     dict(n=1, h=16, w=64, cin=128, cout=448, k=3, res_up=True, prologue=True, force_cfg=7),
+    dict(n=2, h=16, w=64, cin=8, cout=128, k=3, force_cfg=8),             # config 8: first convolution (3 -> 8 padded input channels), K = 72 in 3 MFMA steps
+    dict(n=1, h=24, w=32, cin=16, cout=320, k=3, force_cfg=8),            # Cout tail; K = 144: 5 steps, the last one half zero weights
+    dict(n=1, h=8, w=96, cin=24, cout=192, k=3, force_cfg=8),             # yfcc's 19 -> 24 channels (K = 216: 7 steps; a step straddles two taps)
+    dict(n=3, h=16, w=32, cin=32, cout=64, k=3, force_cfg=8),             # 32 channels: 9 full steps; one half-dead tile
+    dict(n=8, h=128, w=128, cin=8, cout=128, k=3),                        # picked by itself at bench size
     dict(n=8, h=64, w=64, cin=320, cout=320, k=3, prologue=True),          # StableDiffusion level 0 (batch 8, 64x64 latents): picks the tail-tile config by itself
     dict(n=8, h=32, w=32, cin=512, cout=512, k=3, prologue=True),          # 32x32 maps at batch 8: 128-channel tiles with split-K 2 (raw slabs + reduce)
     dict(n=8, h=32, w=32, cin=1024, cout=512, k=3, split=512),             # split-K 4 over a two-source K
@@ -339,7 +344,7 @@ def test_sampler_updates_match_golden():
 @pytest.mark.parametrize("case", [dict(h=16, w=32, cin=64, cout=256, force_cfg=0), dict(h=32, w=32, cin=64, cout=128, force_cfg=1), dict(h=16, w=16, cin=64, cout=192),
                                   dict(h=16, w=64, cin=64, cout=256, force_cfg=4), dict(h=16, w=64, cin=64, cout=256, force_cfg=6),
                                   dict(h=16, w=64, cin=64, cout=128, force_cfg=7), dict(h=16, w=64, cin=64, cout=320, force_cfg=7),
-                                  dict(h=8, w=16, cin=64, cout=64, k=1)])
+                                  dict(h=16, w=64, cin=8, cout=320, force_cfg=8), dict(h=8, w=16, cin=64, cout=64, k=1)])
 def test_fused_output_statistics_feed_groupnorm(case, dtype):
     """conv epilogue statistics (halo + generic kernels) -> GroupNorm coefficients == standalone statistics pass,
     also for a concat of two producers with a group that spans both."""
