@@ -96,7 +96,10 @@ int pmi_igemm_stats_rows(const pmi_igemm_args* a);
  * key 2 = prefer the 8-wave 256-channel halo config over two 4-wave workgroups per CU where the grid allows (default 1);
  * key 6 = allow the weights-direct conv3x3 kernel (default 1); key 7 = its 16x16x32-MFMA form, tile config 6, instead of config 4 (default 1);
  * key 8 = allow its 128-channel form, tile config 7 (4 waves, two workgroups per CU), for Cout % 256 != 0 (default 1);
- * key 13 = allow its first-convolution form, tile config 8 (at most 32 input channels, the whole K in registers) (default 1).
+ * key 13 = allow its first-convolution form, tile config 8 (at most 32 input channels, the whole K in registers) (default 1);
+ * key 9 = query-tile rows per wave of pmi_attn_flash (0 = automatic); key 10 = allow split-K in the weights-direct conv3x3 (default 1);
+ * key 11 = largest split-K factor of the weights-direct GEMM (default 8); key 12 = workgroup count below which that GEMM uses its
+ * 128-column tiles (default 128).  `python bench.py --opt "k=v,..."` sets them for a same-box A/B.
  * The library links no vendor GEMM / BLAS: every kernel it launches is in csrc/. */
 int pmi_set_option(int key, int value);
 
