@@ -63,6 +63,28 @@ def test_weight_packing_layout():
     assert float(p.w[0, 5]) == 0.0 and p.b.tolist() == [1.0, 2.0, 0.0, 0.0]
 
 
+def test_fragment_orders_of_the_weights_direct_kernels():
+    """The host-side fragment packings the weights-direct kernels stream (element (n, k) lands in the lane / register the MFMA A operand
+    expects): config 8's first-convolution order and the GEMM order, against the plain [n][k] packing."""
+    from perceptor_amd.engine.ops import PackedLinear
+    g = torch.Generator().manual_seed(0)
+    lin = PackedLinear(torch.randn(64, 19, 3, 3, generator=g), torch.zeros(64), 0, "cpu", cin_pad=24)     # K = 216: 7 steps of 32, 8 zero columns
+    f = lin.frag_c8()
+    assert f.shape == (2, 7, 2, 4, 16, 8)                      # [N/32][step][16-channel block][k quarter][channel][8 k]
+    w = torch.zeros(64, 7 * 32, dtype=lin.w.dtype)
+    w[:, :lin.K] = lin.w
+    for nb, s_, cb, q, r in [(0, 0, 0, 0, 0), (1, 6, 1, 3, 15), (0, 3, 1, 2, 7), (1, 6, 0, 3, 4)]:
+        assert torch.equal(f[nb, s_, cb, q, r], w[nb * 32 + cb * 16 + r, 32 * s_ + 8 * q: 32 * s_ + 8 * q + 8])
+    assert float(f[:, 6, :, 3].abs().max()) == 0.0            # k 216..223: past 9 taps x 24 channels
+    lin = PackedLinear(torch.randn(64, 160, generator=g), None, 0, "cpu")                                   # K = 160 -> zero-padded to 256
+    f = lin.frag_gemm()
+    assert f.shape == (2, 2, 4, 2, 4, 16, 8)                   # [N/32][K/128][k-step][16-column block][k quarter][column][8 k]
+    for nb, ch, ks, cb, q, r in [(0, 0, 0, 0, 0, 0), (1, 1, 0, 1, 3, 15), (0, 0, 3, 1, 2, 9)]:
+        k0 = 128 * ch + 32 * ks + 8 * q
+        assert torch.equal(f[nb, ch, ks, cb, q, r], lin.w[nb * 32 + cb * 16 + r, k0:k0 + 8])
+    assert float(f[:, 1, 1:].abs().max()) == 0.0               # k >= 160
+
+
 def test_resize_tables_equal_dense_oracle_operator():
     from oracle import clip_vit
     from perceptor_amd.transforms.resize import band_tables
