@@ -24,7 +24,11 @@ namespace {
 // `skip_connection` of a ResBlock whose input is a skip concat (th.cat([h, hs.pop()]), unet.py:647-650), never materialised.
 // NWV: waves per workgroup = 32-column slices per tile: 8 (256-column tiles) or 4 (128-column tiles, 256 threads: N = 128, where a 256-column
 // tile would run half its waves on zeros).
-template <typename T, int MB, bool TWO = false, int NWV = 8>
+// CONV: stride-1 3x3 convolution as the same GEMM (K = 9 taps x Cin, k = tap * Cin + c as PackedLinear packs it; Cin of every source a
+// multiple of 128, so a 128-deep chunk has one tap and one source): the activation row of output pixel m for tap (dy, dx) is the input
+// row of pixel (y + dy - 1, x + dx - 1) -- the staging loads shift their row offset per chunk and read zeros outside the image.  For the
+// maps the conv3x3 kernels' 8 x 32-pixel tiles do not fit or fill (16x16, 8x8, 4x4 at batch 8), with split-K like any long-K GEMM.
+template <typename T, int MB, bool TWO = false, int NWV = 8, bool CONV = false>
 __global__ __launch_bounds__(NWV * 64, 2) void gemm_wd_kernel(const pmi_igemm_args a) {
   constexpr int TM = 16 * MB, BN = NWV * 32, BK = 128, NT = NWV * 64;
   constexpr int ROW = 2 * BK + 32;                     // LDS row pitch (bytes)
@@ -58,15 +62,23 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_wd_kernel(const pmi_igemm_ar
   // activation rows of this tile: rows past M fall outside the resource (zeros)
   const int rows = min(TM, a.M - m0);
   const int K0 = TWO ? a.C0 : a.K;                      // channels of the first source
-  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc((const u16*)a.A0 + (int64_t)m0 * a.lda0, ((int64_t)(rows - 1) * a.lda0 + K0) * 2);
-  const __amdgpu_buffer_rsrc_t rsrc_a1 = TWO ? make_rsrc((const u16*)a.A1 + (int64_t)m0 * a.lda1, ((int64_t)(rows - 1) * a.lda1 + a.C1) * 2) : rsrc_a;
+  // (CONV: the resources cover the whole tensors -- a tap reaches rows of the neighbouring tiles; the host checks they stay below 2 GB)
+  const int64_t mb_ = CONV ? 0 : m0, mr_ = CONV ? a.M : rows;
+  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc((const u16*)a.A0 + mb_ * a.lda0, ((mr_ - 1) * a.lda0 + K0) * 2);
+  const __amdgpu_buffer_rsrc_t rsrc_a1 = TWO ? make_rsrc((const u16*)a.A1 + mb_ * a.lda1, ((mr_ - 1) * a.lda1 + a.C1) * 2) : rsrc_a;
   uint32_t pvo[NPI];                                    // byte offset of this thread's staging pieces inside the tile's rows (k = 0)
   uint32_t pvo1[TWO ? NPI : 1];                         // the same for the second source's row pitch
+  uint32_t pyx[CONV ? NPI : 1];                         // CONV: (y << 16) | x of the piece's output pixel; rows past M: far outside every image
 #pragma unroll
   for (int i = 0; i < NPI; ++i) {
     const int p = tid + NT * i, r = p >> 4, c16 = p & 15;
-    pvo[i] = r < rows ? (uint32_t)(r * a.lda0 + c16 * 8) * 2u : PMI_BUF_OOB;
-    if constexpr (TWO) pvo1[i] = r < rows ? (uint32_t)(r * a.lda1 + c16 * 8) * 2u : PMI_BUF_OOB;
+    const int rg = CONV ? m0 + r : r;                   // CONV: offsets from the tensor's first row
+    pvo[i] = r < rows ? (uint32_t)(rg * a.lda0 + c16 * 8) * 2u : PMI_BUF_OOB;
+    if constexpr (TWO) pvo1[i] = r < rows ? (uint32_t)(rg * a.lda1 + c16 * 8) * 2u : PMI_BUF_OOB;
+    if constexpr (CONV) {
+      const int hwm = rg % (a.H * a.W), y = hwm / a.W;
+      pyx[i] = r < rows ? ((uint32_t)y << 16) | (uint32_t)(hwm - y * a.W) : 0x40004000u;
+    }
   }
   // this wave's weight stream: [chunk][k32 (4)][16-column block (2)][lane][8], 8 KB per chunk, contiguous
   const int64_t wslab = (int64_t)nch_all * 8192;
@@ -76,7 +88,23 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_wd_kernel(const pmi_igemm_ar
 
   uint4 pr[NPI];
   auto load_tile = [&](int chunk, bool live) {
-    if constexpr (TWO) {
+    if constexpr (CONV) {
+      const int cin = a.C0 + a.C1;
+      const int k0 = (c0 + chunk) * BK;                 // wave-uniform: tap and source of this chunk
+      const int tap = __builtin_amdgcn_readfirstlane(k0 / cin), kc = k0 - tap * cin;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      const bool second = TWO && kc >= a.C0;
+      const __amdgpu_buffer_rsrc_t rs = second ? rsrc_a1 : rsrc_a;
+      const uint32_t so = (uint32_t)(second ? kc - a.C0 : kc) * 2u;
+      const int shift = (dy * a.W + dx) * (second ? a.lda1 : a.lda0) * 2;      // bytes from the output pixel's row to the tap's row
+#pragma unroll
+      for (int i = 0; i < NPI; ++i) {
+        const int yy = (int)(pyx[i] >> 16) + dy, xx = (int)(pyx[i] & 0xffffu) + dx;
+        const bool in = live && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;     // zero padding, and rows past M
+        const uint32_t pv = TWO ? (second ? pvo1[i] : pvo[i]) : pvo[i];
+        pr[i] = buf_load16(rs, in ? pv + (uint32_t)shift : PMI_BUF_OOB, so);
+      }
+    } else if constexpr (TWO) {
       const int k0 = (c0 + chunk) * BK;                 // wave-uniform: which tensor this 128-deep chunk comes from (C0 is a multiple of 128)
       const bool second = k0 >= a.C0;
       const __amdgpu_buffer_rsrc_t rs = second ? rsrc_a1 : rsrc_a;
@@ -300,13 +328,19 @@ int launch(const pmi_igemm_args& a, hipStream_t s, int mb) {
   const bool half_tail = (a.N % 256) != 0 && (a.N % 256) <= 128 && a.N < 1024;     // e.g. N = 320: 3 tiles of 128 instead of 2 of 256 (one a quarter full)
   if (a.N < 256 || few || half_tail) {                 // 128-column tiles, four waves, two workgroups per CU
     const dim3 g4(((a.M + 127) / 128) * ((a.N + 127) / 128), 1, a.splitk > 1 ? a.splitk : 1);
-    if (a.A1) hipLaunchKernelGGL((gemm_wd_kernel<T, 8, true, 4>), g4, dim3(256), 0, s, a);
+    if (a.taps == 9) {
+      if (a.A1) hipLaunchKernelGGL((gemm_wd_kernel<T, 8, true, 4, true>), g4, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gemm_wd_kernel<T, 8, false, 4, true>), g4, dim3(256), 0, s, a);
+    } else if (a.A1) hipLaunchKernelGGL((gemm_wd_kernel<T, 8, true, 4>), g4, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gemm_wd_kernel<T, 8, false, 4>), g4, dim3(256), 0, s, a);
     PMI_CHECK_LAUNCH();
     return PMI_OK;
   }
   const dim3 grid(((a.M + tm - 1) / tm) * ((a.N + 255) / 256), 1, a.splitk > 1 ? a.splitk : 1);
-  if (a.A1) hipLaunchKernelGGL((gemm_wd_kernel<T, 8, true>), grid, dim3(512), 0, s, a);        // two-source K: 128-row tiles
+  if (a.taps == 9) {                                   // 3x3 convolution on small maps: 128-row tiles
+    if (a.A1) hipLaunchKernelGGL((gemm_wd_kernel<T, 8, true, 8, true>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((gemm_wd_kernel<T, 8, false, 8, true>), grid, dim3(512), 0, s, a);
+  } else if (a.A1) hipLaunchKernelGGL((gemm_wd_kernel<T, 8, true>), grid, dim3(512), 0, s, a);        // two-source K: 128-row tiles
   else if (mb == 9) hipLaunchKernelGGL((gemm_wd_kernel<T, 9>), grid, dim3(512), 0, s, a);
   else hipLaunchKernelGGL((gemm_wd_kernel<T, 8>), grid, dim3(512), 0, s, a);
   PMI_CHECK_LAUNCH();
@@ -319,7 +353,7 @@ void pmi_gemm_wd_few_wgs(int v) { g_few_wgs = v; }
 
 // rows per tile (128 or 144): fewest rounds of 256 workgroups, then least work per workgroup
 int pmi_gemm_wd_tile_rows(const pmi_igemm_args* a, int splitk) {
-  if (a->A1 || a->N < 256 || ((a->N % 256) != 0 && (a->N % 256) <= 128 && a->N < 1024)) return 128;
+  if (a->A1 || a->taps == 9 || a->N < 256 || ((a->N % 256) != 0 && (a->N % 256) <= 128 && a->N < 1024)) return 128;
   if (splitk <= 1 && (long)((a->M + 127) / 128) * ((a->N + 255) / 256) < g_few_wgs && !a->D2 && !a->aux && a->act != PMI_ACT_GEGLU) return 128;
   int best = 8;
   long best_cost = -1;
@@ -332,11 +366,22 @@ int pmi_gemm_wd_tile_rows(const pmi_igemm_args* a, int splitk) {
 }
 
 // 1 when the weights-direct GEMM takes this call (plain GEMM with fragment-ordered weights), else the generic kernel runs
+int pmi_igemm_halo_allowed(void);     // igemm.hip
+
 extern "C" int pmi_gemm_wd_eligible(const pmi_igemm_args* a) {
-  if (!a->Bf || a->taps != 1 || a->up || a->stride != 1 || a->batch > 1) return 0;
-  if (a->A1 ? (a->C1 <= 0 || (a->C0 % 128) || (a->C1 % 32) || a->splitk > 1 || a->D2 || a->aux || a->act == PMI_ACT_GEGLU) : a->C1 != 0) return 0;
+  if (!a->Bf || (a->taps != 1 && a->taps != 9) || a->up || a->stride != 1 || a->batch > 1) return 0;
+  if (a->taps == 9) {
+    // 3x3 convolution the conv3x3 kernels do not take (small or odd-width maps): whole 128-deep chunks per tap and source, 32-bit offsets
+    if ((a->C0 % 128) || (a->A1 ? (a->C1 <= 0 || (a->C1 % 128)) : a->C1 != 0) || a->D2 || a->aux || a->act == PMI_ACT_GEGLU || a->split_in) return 0;
+    if (a->H <= 0 || a->W <= 0 || a->H >= 0x4000 || a->W >= 0x4000 || a->Hin != a->H || a->Win != a->W || (a->M % (a->H * a->W))) return 0;
+    if (a->K != 9 * (a->C0 + a->C1) || (int64_t)a->M * (a->lda0 > a->lda1 ? a->lda0 : a->lda1) * 2 >= ((int64_t)1 << 31)) return 0;
+    if (pmi_igemm_halo_allowed() && pmi_conv3x3_halo_config(a) >= 0) return 0;
+  } else {
+    if (a->A1 ? (a->C1 <= 0 || (a->C0 % 128) || (a->C1 % 32) || a->splitk > 1 || a->D2 || a->aux || a->act == PMI_ACT_GEGLU) : a->C1 != 0) return 0;
+    if (a->K != a->C0 + a->C1) return 0;
+  }
   if (a->nbias || a->stats || a->pro_a || a->res_up || a->split_out) return 0;
-  if ((a->K % 32) || (a->N % 32) || a->K != a->C0 + a->C1 || a->M < 64) return 0;      // K tail: zero-padded weights; N tail: masked waves
+  if ((a->K % 32) || (a->N % 32) || a->M < 64) return 0;      // K tail: zero-padded weights; N tail: masked waves
   if (a->N < 256 && a->N != 128) return 0;  // N = 128: the four-wave 128-column tiles; other narrow matrices stay on the generic kernel
   if ((a->N % 256) && a->N < 1024) {        // narrow matrix with a partly filled last tile: measured per shape against the generic 128-wide tiles (tools/sd_trace.py)
     const int tail = a->N % 256;

@@ -555,7 +555,7 @@ extern "C" int pmi_igemm_splitk(const pmi_igemm_args* a) {
     if (halo >= 0) return pmi_conv3x3_wd_splitk(a, halo);
   }
   if (a->act == PMI_ACT_GEGLU) return 1;
-  if (a->A1 && pmi_gemm_wd_eligible(a)) return 1;       // two-source weights-direct GEMM: no split-K
+  if (a->A1 && a->taps == 1 && pmi_gemm_wd_eligible(a)) return 1;       // two-source weights-direct GEMM (1x1 skip convolutions): no split-K
   if (pmi_gemm_wd_eligible(a)) {    // weights-direct GEMM: fill the 256 CUs with (row tile x 256-column) workgroups; >= 2 chunks of 128 per split
     const int nch = (a->K + 127) / 128;
     int best = 1;
@@ -577,6 +577,8 @@ extern "C" int pmi_igemm_splitk(const pmi_igemm_args* a) {
   if (s > 16) s = 16;
   return s < 2 ? 1 : s;
 }
+
+int pmi_igemm_halo_allowed(void) { return g_allow_halo; }
 
 extern "C" int pmi_igemm_stats_rows(const pmi_igemm_args* a) {
   if (a->batch > 1 || a->splitk > 1 || a->split_out) return 0;          // (split outputs: the generic fast epilogue and the wd kernel take none)

@@ -6,6 +6,7 @@ used only for device memory.
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 from typing import Optional
 
@@ -18,7 +19,8 @@ from .._hip import ACT_GEGLU, ACT_NONE, DT_F16X2, IgemmArgs, call, ptr
 HALO_ENABLED = True
 SPLITK_ENABLED = True
 WD_ENABLED = True       # weights-direct conv3x3 kernel (csrc/conv_wd.hip) where the shape is eligible
-GEMM_WD_ENABLED = True  # weights-direct GEMM (csrc/gemm_wd.hip) for plain GEMMs
+GEMM_WD_ENABLED = True       # weights-direct GEMM (csrc/gemm_wd.hip) for plain GEMMs
+GEMM_WD_CONV = os.environ.get("PMI_GEMM_WD_CONV", "1") != "0"   # A-B switch: small-map 3x3 convolutions on the weights-direct GEMM (csrc/gemm_wd.hip, CONV)
 FLASH_ENABLED = True    # general flash attention (csrc/attn_flash.hip) instead of batched GEMMs + softmax where the head dim is not 64
 
 
@@ -118,7 +120,7 @@ class PackedLinear:
         """Fragment order for the weights-direct GEMM (csrc/gemm_wd.hip), 16x16x32 MFMA:
         [N/32][K/128][32-deep k-step (4)][16-column block (2)][lane = 16*(k quarter) + column][8 k]."""
         if "gemm" not in self._frag:
-            assert self.taps == 1 and self.n_p % 32 == 0 and self.K % 32 == 0
+            assert self.taps in (1, 9) and self.n_p % 32 == 0 and self.K % 32 == 0     # (taps 9: the GEMM kernel's conv mode, k = tap * Cin + c)
             kp = (self.K + 127) // 128 * 128                                    # K tail: zero weights up to a whole 128-deep chunk
             w = self.w
             if kp != self.K:
@@ -238,6 +240,10 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
     if lin.self_concat:        # precise mode, fp32 weights: their low part multiplies the SAME input again as a second source
         assert a.A1 is None
         a.A1, a.C1, a.lda1 = a.A0, a.C0, a.lda0
+    if conv and lin.taps == 9 and stride == 1 and not up and not res_up and GEMM_WD_ENABLED and GEMM_WD_CONV and not lin.split and not a.Bf \
+            and not a.pro_a and nbias is None and lin.n_p % 32 == 0 and c0 % 128 == 0 and c1 % 128 == 0:
+        a.Bf = 1           # a 3x3 convolution the conv3x3 kernels do not take (16x16 / 8x8 maps): the weights-direct GEMM's conv mode, if it does
+        a.Bf = ptr(lin.frag_gemm()) if _hip.lib().pmi_gemm_wd_eligible(C.byref(a)) else None
     if SPLITK_ENABLED:
         sk = _hip.lib().pmi_igemm_splitk(C.byref(a))
         if sk > 1:   # few output tiles, long K: split the reduction over grid.z into fp32 slabs
