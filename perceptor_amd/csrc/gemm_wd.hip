@@ -380,7 +380,10 @@ extern "C" int pmi_gemm_wd_eligible(const pmi_igemm_args* a) {
     if (a->A1 ? (a->C1 <= 0 || (a->C0 % 128) || (a->C1 % 32) || a->splitk > 1 || a->D2 || a->aux || a->act == PMI_ACT_GEGLU) : a->C1 != 0) return 0;
     if (a->K != a->C0 + a->C1) return 0;
   }
-  if (a->nbias || a->stats || a->pro_a || a->res_up || a->split_out) return 0;
+  // per-sample bias (the timestep projection added behind a ResBlock's first convolution): conv mode only, and only with split-K -- the
+  // reduce kernel adds it; splitk == 0 is the caller's query before it has chosen the split (pmi_igemm re-checks with the final value)
+  if (a->nbias && (a->taps != 9 || a->splitk == 1)) return 0;
+  if (a->stats || a->pro_a || a->res_up || a->split_out) return 0;
   if ((a->K % 32) || (a->N % 32) || a->M < 64) return 0;      // K tail: zero-padded weights; N tail: masked waves
   if (a->N < 256 && a->N != 128) return 0;  // N = 128: the four-wave 128-column tiles; other narrow matrices stay on the generic kernel
   if ((a->N % 256) && a->N < 1024) {        // narrow matrix with a partly filled last tile: measured per shape against the generic 128-wide tiles (tools/sd_trace.py)

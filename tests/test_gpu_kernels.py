@@ -148,6 +148,28 @@ def test_igemm_conv(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [dict(n=8, h=16, w=16, cin=1280, cout=1280), dict(n=8, h=8, w=8, cin=2560, cout=1280, split=1280),
+                                  dict(n=2, h=8, w=8, cin=128, cout=256)])      # the last one: short K, no split-K -> the generic kernel adds the bias
+def test_small_map_conv_with_per_sample_bias(case, dtype):
+    """StableDiffusion's ResBlock conv1 + timestep projection (openaimodel.py `h + emb_out[..., None, None]`) on 16x16 / 8x8 maps: the
+    weights-direct GEMM's conv mode with split-K, the per-sample bias added by the reduce kernel; vs fp32 torch on pre-rounded operands."""
+    from perceptor_amd.engine import ops
+    from perceptor_amd._hip import dtype_code
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    n, h, w, cin, cout = (case[z] for z in ("n", "h", "w", "cin", "cout"))
+    x = _r(torch.randn(n, cin, h, w, generator=g), dtype)
+    wt = _r(torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5, dtype)
+    b, nb = torch.randn(cout, generator=g) * 0.1, torch.randn(n, cout, generator=g)
+    ref = F.silu(F.conv2d(x, wt, b, padding=1) + nb[:, :, None, None])
+    lin = ops.PackedLinear(wt, b, dtype_code(dtype), dev, sources=(case["split"], cin - case["split"]) if "split" in case else None)
+    xs = _nhwc(x, dtype).to(dev)
+    a0, a1 = (xs[..., :case["split"]].contiguous(), xs[..., case["split"]:].contiguous()) if "split" in case else (xs, None)
+    out = ops.igemm(a0, lin, a1=a1, nbias=nb.to(dev), act=2)
+    _check(out[..., :cout].permute(0, 3, 1, 2).cpu(), ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_igemm_linear_ragged_and_nbias(dtype):
     from perceptor_amd.engine import ops
     from perceptor_amd._hip import dtype_code
