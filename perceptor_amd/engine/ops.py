@@ -283,7 +283,8 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
     if GEMM_TRACE is not None:
         kind = "conv" if conv and (lin.taps == 9 or up or stride == 2) else "gemm"
         desc = f"{kind} M={m} N={lin.n_p} K={lin.K} taps={lin.taps}{' up' if up else ''}{' s2' if stride == 2 else ''} splitk={a.splitk}" \
-               f" halo={_hip.lib().pmi_conv3x3_halo_config(C.byref(a)) if HALO_ENABLED else -1}{' res' if residual is not None else ''}{' f32out' if a.out_f32 else ''}"
+               f" halo={_hip.lib().pmi_conv3x3_halo_config(C.byref(a)) if HALO_ENABLED else -1} wd={int(bool(a.Bf) and bool(_hip.lib().pmi_gemm_wd_eligible(C.byref(a))))}" \
+               f"{' res' if residual is not None else ''}{' f32out' if a.out_f32 else ''}{' nbias' if nbias is not None else ''}{' stats' if a.stats else ''}"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         call("pmi_igemm", C.byref(a))
