@@ -222,10 +222,17 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
         a.Bf = ptr(lin.frag16(64)) if cfg == 6 else ptr(lin.frag16(32)) if cfg == 7 else ptr(lin.frag(64)) if cfg == 4 else ptr(lin.frag_c8()) if cfg == 8 else None
     if pre_out is not None or act_grad_of is not None:
         a.D2, a.aux, a.aux_act = ptr(pre_out), ptr(act_grad_of), act_grad
-    if GEMM_WD_ENABLED and lin.taps == 1 and not lin.split and not up and stride == 1 and lin.n_p % 32 == 0 and lin.K % 32 == 0 \
-            and nbias is None and not want_stats and prologue is None:
+    wd_ok = GEMM_WD_ENABLED and lin.taps == 1 and not lin.split and not up and stride == 1 and lin.n_p % 32 == 0 and lin.K % 32 == 0 \
+        and nbias is None and prologue is None
+    if wd_ok and want_stats:
+        # the weights-direct GEMM has no statistics epilogue; the generic kernel has none either once it splits K (attention proj_out on
+        # 16x16 / 8x8 maps): then the faster GEMM runs and the consumer's GroupNorm takes its statistics pass as before
+        wd_ok = SPLITK_ENABLED and _hip.lib().pmi_igemm_splitk(C.byref(a)) > 1
+    if wd_ok:
         a.Bf = 1                               # plain GEMM: ask whether the weights-direct kernel (csrc/gemm_wd.hip) takes this shape ...
         a.Bf = ptr(lin.frag_gemm()) if _hip.lib().pmi_gemm_wd_eligible(C.byref(a)) else None      # ... and only then pack its weight order
+        if a.Bf:
+            want_stats = False
     if prologue is not None:
         ca, cb, pact = prologue
         if HALO_ENABLED and not lin.split and _hip.lib().pmi_conv3x3_halo_config(C.byref(a)) >= 0:
