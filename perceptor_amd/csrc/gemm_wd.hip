@@ -376,6 +376,9 @@ extern "C" int pmi_gemm_wd_eligible(const pmi_igemm_args* a) {
     if (a->H <= 0 || a->W <= 0 || a->H >= 0x4000 || a->W >= 0x4000 || a->Hin != a->H || a->Win != a->W || (a->M % (a->H * a->W))) return 0;
     if (a->K != 9 * (a->C0 + a->C1) || (int64_t)a->M * (a->lda0 > a->lda1 ? a->lda0 : a->lda1) * 2 >= ((int64_t)1 << 31)) return 0;
     if (pmi_igemm_halo_allowed() && pmi_conv3x3_halo_config(a) >= 0) return 0;
+    // below 512 output pixels in all (4x4 maps at batch 4, 8x8 at batch 1..4) a 128-row tile is mostly padding and the generic kernel's
+    // 16-way split is as fast or faster (tools/gemm_trace.py --config c2: M = 64: 33 vs 31 us, M = 256: equal, M = 1024: 29.5 vs 33.4)
+    if (a->M < 512) return 0;
   } else {
     if (a->A1 ? (a->C1 <= 0 || (a->C0 % 128) || (a->C1 % 32) || a->splitk > 1 || a->D2 || a->aux || a->act == PMI_ACT_GEGLU) : a->C1 != 0) return 0;
     if (a->K != a->C0 + a->C1) return 0;

@@ -94,9 +94,9 @@ def _check(got, ref, dtype, extra=1.0):
     # small / odd-width maps with Cin % 128 == 0: the weights-direct GEMM's conv mode (csrc/gemm_wd.hip CONV), split-K, two sources, row tails
     dict(n=8, h=16, w=16, cin=1024, cout=1024, k=3),
     dict(n=8, h=8, w=8, cin=2048, cout=1024, k=3, split=1024),
-    dict(n=2, h=12, w=20, cin=128, cout=256, k=3),                         # M = 480: a partly filled row tile; short K (no split)
+    dict(n=3, h=12, w=20, cin=128, cout=256, k=3),                         # M = 720: a partly filled row tile; short K (no split)
     dict(n=4, h=16, w=16, cin=640, cout=320, k=3),                         # StableDiffusion: 128-column tiles with an N tail
-    dict(n=3, h=4, w=4, cin=256, cout=128, k=3, f32=True),                 # 4x4 maps (every pixel touches the border), fp32 out
+    dict(n=32, h=4, w=4, cin=256, cout=128, k=3, f32=True),                # 4x4 maps (every pixel touches the border), fp32 out
     dict(n=8, h=16, w=16, cin=1536, cout=1024, k=3, split=1024),           # second source 512 channels
 ])
 def test_igemm_conv(case, dtype):
