@@ -386,7 +386,8 @@ extern "C" int pmi_gemm_wd_eligible(const pmi_igemm_args* a) {
   // per-sample bias (the timestep projection added behind a ResBlock's first convolution): conv mode only, and only with split-K -- the
   // reduce kernel adds it; splitk == 0 is the caller's query before it has chosen the split (pmi_igemm re-checks with the final value)
   if (a->nbias && (a->taps != 9 || a->splitk == 1)) return 0;
-  if (a->stats || a->pro_a || a->res_up || a->split_out) return 0;
+  if (a->res_up && (a->taps != 9 || a->splitk == 1)) return 0;      // (an up-sampled residual: likewise the reduce kernel's)
+  if (a->stats || a->pro_a || a->split_out) return 0;
   if ((a->K % 32) || (a->N % 32) || a->M < 64) return 0;      // K tail: zero-padded weights; N tail: masked waves
   if (a->N < 256 && a->N != 128) return 0;  // N = 128: the four-wave 128-column tiles; other narrow matrices stay on the generic kernel
   if ((a->N % 256) && a->N < 1024) {        // narrow matrix with a partly filled last tile: measured per shape against the generic 128-wide tiles (tools/sd_trace.py)

@@ -248,7 +248,7 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
         assert a.A1 is None
         a.A1, a.C1, a.lda1 = a.A0, a.C0, a.lda0
     conv_gemm = False
-    if conv and lin.taps == 9 and stride == 1 and not up and not res_up and GEMM_WD_ENABLED and GEMM_WD_CONV and not lin.split and not a.Bf \
+    if conv and lin.taps == 9 and stride == 1 and not up and GEMM_WD_ENABLED and GEMM_WD_CONV and not lin.split and not a.Bf \
             and not a.pro_a and lin.n_p % 32 == 0 and c0 % 128 == 0 and c1 % 128 == 0:
         a.Bf = 1           # a 3x3 convolution the conv3x3 kernels do not take (16x16 / 8x8 maps): the weights-direct GEMM's conv mode, if it does
         a.Bf = ptr(lin.frag_gemm()) if _hip.lib().pmi_gemm_wd_eligible(C.byref(a)) else None
@@ -263,8 +263,8 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
                 a.reserved3 = 1
                 call("pmi_igemm", C.byref(a))
                 return ("slabs", ws, sk)
-    if conv_gemm and nbias is not None and a.splitk <= 1:
-        a.Bf = None            # a per-sample bias is added by the split-K reduce kernel only: unsplit, the generic kernel takes the call
+    if conv_gemm and (nbias is not None or res_up) and a.splitk <= 1:
+        a.Bf = None            # a per-sample bias / up-sampled residual is the split-K reduce kernel's: unsplit, the generic kernel takes the call
     if want_stats:
         rows = _hip.lib().pmi_igemm_stats_rows(C.byref(a))
         if rows > 0:   # fused per-channel (sum, sumsq) of the output for the next GroupNorm

@@ -98,6 +98,7 @@ def _check(got, ref, dtype, extra=1.0):
     dict(n=4, h=16, w=16, cin=640, cout=320, k=3),                         # StableDiffusion: 128-column tiles with an N tail
     dict(n=32, h=4, w=4, cin=256, cout=128, k=3, f32=True),                # 4x4 maps (every pixel touches the border), fp32 out
     dict(n=8, h=16, w=16, cin=1536, cout=1024, k=3, split=1024),           # second source 512 channels
+    dict(n=8, h=16, w=16, cin=1024, cout=1024, k=3, res_up=True),          # up ResBlock tail on a small map: the reduce kernel adds nearest-up(skip)
 ])
 def test_igemm_conv(case, dtype):
     from perceptor_amd.engine import ops
