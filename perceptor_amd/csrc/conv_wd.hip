@@ -28,6 +28,9 @@
 #include "common.h"
 #include "../../include/perceptor_hip.h"
 
+#ifndef WLG
+#define WLG 1        // which group of a (dx, step) pair issues the next pair's weight loads: 0 = the first (two groups of latency cover), 1 = the second
+#endif
 #ifndef WD_ILV
 #define WD_ILV 2     // (4 until the last sweep: 2 leaves the 128-channel tiles 12 instead of 32 B/lane of scratch and measures +2 % there) VALU instructions of the patch staging the scheduler is asked to place behind each output row's MFMAs
 #endif
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
     const int gbase = chunk * WGC;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      if (MF16) { if ((g & 1) == 0) load_wg(((g >> 1) + 1 + PH) & 1, gbase + (g >> 1) + 1); }     // the next (dx, step) pair, one pair ahead
+      if (MF16) { if ((g & 1) == WLG) load_wg(((g >> 1) + 1 + PH) & 1, gbase + (g >> 1) + 1); }     // the next (dx, step) pair: issued in the pair's second group (WLG 1), so that the store-slot groups hold ONE weight set
       else load_wg((g + 2) % 3, gbase + g + 2);                                              // two groups ahead
       const bool store_slot = g % SG == 0 && g / SG < NPI;            // stores piece g / SG from `pr`
       const int lp = (g + 1 == NG) ? 0 : (g - (SG - 1)) / SG + 1;     // piece whose load is issued in this group (if load_slot)

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_wd_kernel(const pmi_igemm_ar
   const uint32_t wvo = (uint32_t)lane * 16u + (uint32_t)c0 * 8192u;
 
   uint4 pr[NPI];
+  const int kc16 = (tid & 15) * 8;                      // first channel of this thread's staging pieces inside a 128-deep chunk (NT is a multiple of 16)
   auto load_tile = [&](int chunk, bool live) {
     if constexpr (CONV) {
       const int cin = a.C0 + a.C1;
@@ -109,11 +110,15 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_wd_kernel(const pmi_igemm_ar
       const bool second = k0 >= a.C0;
       const __amdgpu_buffer_rsrc_t rs = second ? rsrc_a1 : rsrc_a;
       const uint32_t so = (uint32_t)(second ? k0 - a.C0 : k0) * 2u;
+      // K tail (C1 a multiple of 32 only): pieces past the source's last channel must read zeros, not the next row -- a NaN / Inf there
+      // would survive the multiplication by the zero-padded weights
+      const bool cut = (second ? k0 - a.C0 + kc16 >= a.C1 : false);
 #pragma unroll
-      for (int i = 0; i < NPI; ++i) pr[i] = buf_load16(rs, live ? (second ? pvo1[i] : pvo[i]) : PMI_BUF_OOB, so);
+      for (int i = 0; i < NPI; ++i) pr[i] = buf_load16(rs, (live && !cut) ? (second ? pvo1[i] : pvo[i]) : PMI_BUF_OOB, so);
     } else {
+      const bool cut = (c0 + chunk) * BK + kc16 >= a.K;         // K tail, as above (only the last chunk of a K that is not a multiple of 128)
 #pragma unroll
-      for (int i = 0; i < NPI; ++i) pr[i] = buf_load16(rsrc_a, live ? pvo[i] : PMI_BUF_OOB, (uint32_t)(c0 + chunk) * (BK * 2));
+      for (int i = 0; i < NPI; ++i) pr[i] = buf_load16(rsrc_a, (live && !cut) ? pvo[i] : PMI_BUF_OOB, (uint32_t)(c0 + chunk) * (BK * 2));
     }
   };
   auto store_tile = [&](char* buf) {

@@ -640,6 +640,7 @@ extern "C" int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream) {
   if (a->stats && a->stats_p != pmi_igemm_stats_rows(a)) return PMI_ERR_ARG;
   if (a->splitk > 1 && (!a->ws || a->batch > 1 || (halo >= 0 && a->splitk != pmi_conv3x3_wd_splitk(a, halo)) || (a->N & 3) || a->stats)) return PMI_ERR_ARG;
   if (a->act == PMI_ACT_GEGLU && !pmi_gemm_wd_eligible(a)) return bad_arg(__LINE__);     // the gated epilogue exists in the weights-direct GEMM only
+  if ((a->D2 || a->aux) && !pmi_gemm_wd_eligible(a)) return bad_arg(__LINE__);           // so do the second output / activation-gradient epilogues: no other kernel would honour them
   if (pmi_gemm_wd_eligible(a) && !((a->nbias || a->res_up) && a->splitk <= 1)) {      // (a per-sample bias / up-sampled residual needs the reduce kernel: split-K only)
     const int rc = pmi_gemm_wd_launch(a, stream);
     if (rc != PMI_OK || a->splitk <= 1 || a->reserved3 == 1) return rc;      // reserved3 = 1: the caller consumes the raw slabs (fused reduce + LayerNorm)

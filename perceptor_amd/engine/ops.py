@@ -327,9 +327,18 @@ def interleave_geglu(weight: torch.Tensor, bias: Optional[torch.Tensor]):
 
 
 def fused_mlp_epilogues(lin: PackedLinear, m: int) -> bool:
-    """True when a plain 16-bit-output GEMM of m rows with these weights runs in the weights-direct kernel, whose epilogue can also
-    write the pre-activation value (pre_out) and multiply by an activation gradient (act_grad_of)."""
-    return GEMM_WD_ENABLED and lin.taps == 1 and not lin.split and lin.n_p % 256 == 0 and lin.K % 128 == 0 and m >= 64
+    """True when a plain 16-bit-output GEMM of m rows with these weights runs in the weights-direct kernel UNSPLIT, whose epilogue can also
+    write the pre-activation value (pre_out) and multiply by an activation gradient (act_grad_of).  The library decides (its split-K cost
+    model and A/B options included): pmi_igemm rejects D2 / aux on any other route."""
+    if not (GEMM_WD_ENABLED and lin.taps == 1 and not lin.split and lin.n_p % 32 == 0 and lin.K % 32 == 0):
+        return False
+    a = IgemmArgs()
+    a.taps, a.stride, a.M, a.N, a.K, a.C0, a.batch, a.batch_inner, a.hw = 1, 1, m, lin.n_p, lin.K, lin.K, 1, 1, 1
+    a.lda0, a.ldb, a.ldd, a.dtype, a.alpha = lin.K, lin.K, lin.n_p, lin.dt, 1.0
+    a.Bf, a.D2 = 1, 1                        # non-null markers: eligibility is asked for a call WITH the second output
+    if SPLITK_ENABLED and _hip.lib().pmi_igemm_splitk(C.byref(a)) > 1:
+        return False
+    return bool(_hip.lib().pmi_gemm_wd_eligible(C.byref(a)))
 
 
 def bgemm(A: torch.Tensor, B: torch.Tensor, D: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldb: int, ldd: int,

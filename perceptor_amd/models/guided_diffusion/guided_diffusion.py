@@ -141,6 +141,11 @@ class GuidedDiffusion(torch.nn.Module):
         n = diffused_images.shape[0]
         if idx.numel() == 1 and n > 1:
             idx = idx.expand(n)
+        if torch.is_grad_enabled() and diffused_images.requires_grad:
+            # upstream this call is differentiable (guided_diffusion.py:125-133: autocast, no no_grad); the HIP ADM engine has no input-gradient
+            # pass yet, and returning a detached eps would hand the caller None gradients without a word
+            raise NotImplementedError("GuidedDiffusion.predicted_noise: gradients to diffused_images are not implemented for the ADM UNet engine; "
+                                      "call it under torch.no_grad() or pass diffused_images.detach() (VelocityDiffusion supports the gradient)")
         return self._need_engine().forward(diffused_images.to(self.device), idx, out_channels=3)
 
     def predictions(self, diffused_images, indices) -> Predictions:

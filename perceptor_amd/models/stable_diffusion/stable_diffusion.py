@@ -86,11 +86,16 @@ class StableDiffusion(torch.nn.Module):
         self.vae_original_requires_grads = [False for _ in self.vae.parameters()]
         self._bpe_path, self._tokenizer = bpe_path, None
         self._engines = {}
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module._engines.clear())
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._drop_caches())
 
     # ---- engines (packed 16-bit copies, rebuilt after .to() / load_state_dict) -------------------------------
-    def _apply(self, fn, *a, **k):
+    def _drop_caches(self):
         self._engines.clear()
+        self.__dict__.pop("_pair_key", None)
+        self.__dict__.pop("_pair_ctx", None)
+
+    def _apply(self, fn, *a, **k):
+        self._drop_caches()
         return super()._apply(fn, *a, **k)
 
     def _engine(self, which):
@@ -224,9 +229,14 @@ class StableDiffusion(torch.nn.Module):
         if idx.numel() == 1 and n > 1:
             idx = idx.expand(n)
         ex = lambda c: c.encodings.expand(n, -1, -1) if c.encodings.shape[0] == 1 and n > 1 else c.encodings
-        key = (neutral.encodings.data_ptr(), positive.encodings.data_ptr(), n)
-        if self.__dict__.get("_pair_key") != key:          # one context tensor per (prompt pair, batch): keeps the engine's k|v cache valid
-            self.__dict__["_pair_key"], self.__dict__["_pair_ctx"] = key, torch.cat([ex(neutral), ex(positive)], dim=0).contiguous()
+        # One context tensor per (prompt pair, batch) keeps the engine's k|v cache valid across the steps of a chain.  The cache entry HOLDS the two
+        # encodings tensors (their addresses cannot be recycled for another prompt while it lives) and is compared by identity and
+        # in-place version (an edited encodings tensor, e.g. prompt weighting, is a new context).
+        ne, pe = neutral.encodings, positive.encodings
+        key = self.__dict__.get("_pair_key")
+        if key is None or key[0] is not ne or key[1] is not pe or key[2:] != (ne._version, pe._version, n):
+            self.__dict__["_pair_key"] = (ne, pe, ne._version, pe._version, n)
+            self.__dict__["_pair_ctx"] = torch.cat([ex(neutral), ex(positive)], dim=0).contiguous()
         x = diffused_latents.to(self.device)
         eps = self._engine("unet").forward(torch.cat([neutral.input(x), positive.input(x)], dim=0), torch.cat([idx, idx], dim=0), self._pair_ctx)
         mk = lambda e: Predictions(from_diffused_latents=diffused_latents, from_indices=idx, predicted_noise=e.contiguous(),

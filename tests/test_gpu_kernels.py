@@ -242,6 +242,33 @@ def test_gemm_wd(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_wd_k_tail_does_not_read_the_next_row(dtype):
+    """K = 320 is 2.5 staging chunks of 128; the tail half-chunk must read zeros, not the first channels of the next row (another
+    sample): a NaN / Inf planted there would survive the multiplication by the zero-padded weights.  Rows are views into a wider buffer
+    whose columns K..K+63 hold NaN -- exactly the bytes the unmasked tail read."""
+    from perceptor_amd.engine import ops
+    from perceptor_amd._hip import dtype_code
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    m, k, n, ld = 1024, 320, 960, 384
+    td = torch.float16 if dtype == "f16" else torch.bfloat16
+    x = _r(torch.randn(m, k, generator=g), dtype)
+    wt = _r(torch.randn(n, k, generator=g) / k ** 0.5, dtype)
+    buf = torch.full((m, ld), float("nan"), dtype=td, device=dev)
+    buf[:, :k] = x.to(td).to(dev)
+    lin = ops.PackedLinear(wt, None, dtype_code(dtype), dev)
+    out = ops.igemm(buf[:, :k], lin)
+    assert torch.isfinite(out).all()
+    _check(out.cpu(), x @ wt.T, dtype)
+    # contiguous rows: the bytes behind row r are row r + 1; NaN in row r + 1 must not reach row r
+    x2 = x.clone()
+    x2[1::2] = float("nan")
+    out2 = ops.igemm(x2.to(td).to(dev), lin)
+    assert torch.isfinite(out2[0::2]).all()
+    _check(out2[0::2].cpu(), (x @ wt.T)[0::2], dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("m, k, f", [(4096, 320, 1280), (1000, 640, 2560), (300, 1280, 5120), (40, 320, 1280)])
 def test_geglu_linear_fused_epilogue_and_fallback(m, k, f, dtype):
     """GEGLU feed-forward projection (stable_diffusion/attention.py:346-348): value * gelu(gate) from the weights-direct GEMM's epilogue

@@ -150,6 +150,36 @@ def test_class_surface_step_cfg_decode_encode_vs_oracle():
     assert strong.dynamic_threshold(0.95).predicted_noise.shape == x.shape        # decode -> clamp -> encode round trip runs
 
 
+def test_predictions_pair_context_cache_follows_the_prompt():
+    """the (prompt pair -> context) cache of predictions_pair must not survive a new prompt whose encodings land on a recycled
+    address, nor an in-place edit of the encodings; it must survive unchanged conditionings (one k|v projection per chain)."""
+    import gc
+    m = _tiny_model()
+    x = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(5)).cuda()
+    ids_a = torch.tensor([[518, 5, 9, 300, 519] + [519] * 11])
+    ids_b = torch.tensor([[518, 77, 41, 8, 12, 519] + [519] * 10])
+    ids_n = torch.tensor([[518, 519] + [519] * 14])
+    neu, pos = m.conditioning(token_ids=ids_n), m.conditioning(token_ids=ids_a)
+    _, po_a = m.predictions_pair(x, 600, neu, pos)
+    ctx_a = m._pair_ctx
+    m.predictions_pair(x, 560, neu, pos)
+    assert m._pair_ctx is ctx_a                                   # same conditionings: the context (and the engine's k|v cache) is reused
+    want_a = po_a.predicted_noise.clone()
+    del neu, pos, po_a
+    gc.collect()
+    torch.cuda.empty_cache()
+    neu, pos = m.conditioning(token_ids=ids_n), m.conditioning(token_ids=ids_b)      # may reuse the freed addresses
+    _, po_b = m.predictions_pair(x, 600, neu, pos)
+    sep_b = m.predictions(x, 600, pos).predicted_noise
+    assert _err(po_b.predicted_noise.cpu(), sep_b.cpu())[0] < 2e-3
+    assert _err(po_b.predicted_noise.cpu(), want_a.cpu())[0] > 1e-2          # and it is not prompt A's answer
+    pos.encodings.mul_(0)                                          # in-place edit: a new context
+    _, po_0 = m.predictions_pair(x, 600, neu, pos)
+    sep_0 = m.predictions(x, 600, pos).predicted_noise
+    assert _err(po_0.predicted_noise.cpu(), sep_0.cpu())[0] < 2e-3
+    assert _err(po_0.predicted_noise.cpu(), po_b.predicted_noise.cpu())[0] > 1e-3
+
+
 def test_sample_loop_schedule_and_errors():
     from perceptor_amd import models
     from perceptor_amd.utils.tokenizer import ClipTokenizer
