@@ -28,7 +28,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "precise": 2500.0}   # precise = f16 MFMA on hi + lo pairs: twice the MFMA work per algorithmic FLOP   # dense MFMA peak, MI355X_MICROARCH.md (never the 2:1-sparse figure)
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "precise": 2500.0, "mixed": 2500.0}   # precise = f16 MFMA on hi + lo pairs: twice the MFMA work per algorithmic FLOP   # dense MFMA peak, MI355X_MICROARCH.md (never the 2:1-sparse figure)
 
 # forward GFLOP / sample (torch flop counter on the reference modules)
 UNET_GFLOP = {"standard": {512: 3964.7, 256: 989.0}, "pixelart": {256: 497.5, 64: 497.5 / 16},
@@ -53,8 +53,10 @@ def parse():
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--config", default="c5", choices=sorted(CONFIGS))
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "precise"],
-                   help="UNet arithmetic: bf16 / f16 single-pass MFMA, or precise (hi + lo f16 pairs, eps max-abs error < 1e-3 vs the fp32 reference)")
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "mixed", "precise"],
+                   help="UNet arithmetic: bf16 / f16 single-pass MFMA; mixed (GD UNets: hi + lo storage, doubled operands on the layers the error "
+                        "budget names: eps max-abs error < 1e-3 vs the fp32 reference at ~1.4x the f16 MFMA work); precise (hi + lo everywhere, 2x)")
+    p.add_argument("--no-modes", action="store_true", help="skip the short timing + parity of the other precision modes after the timed region (\"modes\" in the line)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--opt", default="", help="A/B switches of the library: comma-separated key=value pairs for pmi_set_option (e.g. 10=0: no conv split-K)")
     p.add_argument("--sd-bf16", action="store_true", help="config c4: bf16 operands instead of the f16 the reference runs SD in")
@@ -172,6 +174,44 @@ def cpu_baseline(model_name, res, nb, clip_arch, clip_loss, hip_model, dev, seed
     sample = (f"one full oracle step at batch 1 @{sres}x{sres}: UNet {t_unet:.2f}s + CLIP {clip_arch or 'none'} fwd+bwd and guidance {t_clip:.2f}s + update {t_upd:.3f}s; "
               f"UNet/update scaled x{scale_px:.0f} (batch x pixels), CLIP leg x{nb} (batch)")
     return sec_step, sample, cores, parity
+
+
+def precision_modes(a, out, model_name, res, eager_step, images, dev, steps=6):
+    """After the timed region (rank 0, N = 1): the same step in the other precision modes of the UNet, `steps` steps each after 2 of warm-up,
+    HIP-event time on the launch stream, and the eps parity of each mode on the cpu_baseline's sample (batch 1 @256x256 vs the CPU fp32
+    oracle).  The timed mode's own entry repeats the line's figures.  north_star's bar is eps max-abs error < 1e-3."""
+    from oracle import adm_unet
+    from perceptor_amd import models
+    from perceptor_amd.utils.synth import seeded_noise, synth_state_dict
+    modes = {a.dtype: {"ms_per_step": out["ms_per_step"], "eps_max_abs_err": (out.get("parity") or {}).get("eps_max_abs_err"), "timed": True}}
+    cfg = adm_unet.openimages_config() if model_name == "standard" else adm_unet.pixelart_config()
+    sres = min(res, 256)
+    x = seeded_noise((1, 3, sres, sres), 1234)
+    fi = torch.tensor([600])
+    eps_ref = None
+    for name in ("bf16", "f16", "mixed"):
+        if name in modes:
+            continue
+        m = models.GuidedDiffusion(model_name, dtype=name).to(dev)
+        img = images.clone()
+        for i in range(2):
+            img = eager_step(img, i, m)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(steps):
+            img = eager_step(img, 2 + i, m)
+        e1.record()
+        torch.cuda.synchronize()
+        entry = {"ms_per_step": round(e0.elapsed_time(e1) / steps, 3), "steps": steps, "outputs_finite": bool(torch.isfinite(img).all().item())}
+        if eps_ref is None:
+            sd = synth_state_dict(adm_unet.state_dict_shapes(cfg), 0)
+            eps_ref = adm_unet.adm_unet_forward(sd, cfg, x, fi)[:, :3]
+        eps = m.predicted_noise((x * 0.5 + 0.5).to(dev), fi.to(dev)).float().cpu()
+        entry["eps_max_abs_err"] = float((eps - eps_ref).abs().max())
+        modes[name] = entry
+        del m
+        torch.cuda.empty_cache()
+    return modes
 
 
 def main_sd(a, rank, world, dev, dist):
@@ -328,13 +368,14 @@ def main():
     n_sched = max(a.steps + a.warmup + 1, 50)
     sched = model.schedule_ts(n_steps=n_sched).to(dev) if is_v else model.schedule_indices(n_steps=n_sched, rho=7.0)
 
-    def one_step(images, i):
+    def one_step(images, i, model=model):
         fi, ti = sched[i % len(sched)]
         pred = model.predictions(images, fi, cond) if is_v else model.predictions(images, fi)
         if clip_loss is not None:
             _, grad = clip_loss.loss_and_grad(pred.denoised_images, n_total=nb * world)
             pred = pred.guided(grad, guidance_scale=0.5, clamp_value=1e-6)
         return pred.step(ti)
+    eager_step = one_step
 
     if a.graph:
         from perceptor_amd.engine.graph import GraphedStep
@@ -374,10 +415,17 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    rank_ms = [elapsed / a.steps * 1e3]
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        mine = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [float(t.item()) / a.steps * 1e3 for t in every]
+        tmax = mine.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {a.gpus}")
     finite = bool(torch.isfinite(images).all().item())
 
     if rank == 0:
@@ -440,9 +488,12 @@ def main():
                                    + ", DDIM eta=0, synthetic weights", "name": a.config,
                        "global_batch": nb * world, "parallelism": f"replica-sharded chains x{world}"},
             "outputs_finite": finite,
-            "rccl_ranks": world if dist is not None else 0,
+            "rccl_ranks": dist.get_world_size() if dist is not None else 0,
+            "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},     # skew between the ranks' own clocks
             "roofline": roof,
         }
+        if dist is not None:
+            assert out["rccl_ranks"] == a.gpus, (out["rccl_ranks"], a.gpus)
         if not a.no_cpu_baseline and world == 1:
             if is_v:
                 t_unet, sres, cores = cpu_baseline_v(model_name, res)
@@ -457,6 +508,8 @@ def main():
                                    "sample": sample}
             if parity is not None:
                 out["parity"] = parity
+        if not a.no_modes and world == 1 and not is_v and a.config in ("c5", "c2", "c5-noclip"):
+            out["modes"] = precision_modes(a, out, model_name, res, eager_step, images, dev)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

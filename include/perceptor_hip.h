@@ -71,7 +71,11 @@ typedef struct {
   int32_t split_out;   /* "precise" mode (dtype 2): D (and a 16-bit R) hold hi + lo f16 pairs in groups of split_out (8 or 32) logical channels,
                         * ldd / ldr count 16-bit elements of the 2N-wide rows; 0 = plain.  A split INPUT needs no flag: it is a tensor with 2 Cin
                         * channels whose weights are duplicated along K by the caller.  Generic kernel only (no LDS-halo config). */
-  int32_t split_in;    /* 1: the inputs are precise (hi + lo) tensors -> generic kernel only (a fused prologue would act on the two parts separately) */
+  int32_t split_in;    /* 1: the inputs are precise (hi + lo) tensors whose 2 Cin physical channels are the K dimension (C0 / C1 / K count them; weights
+                        *    duplicated along K).  A fused prologue is taken by the weights-direct conv3x3 configs 6 / 7 only: they stage (hi, lo) PAIRS,
+                        *    apply it to the value hi + lo and split the result again (chunk K order [yh of ck/2 channels | their yl]: Bf packed so).
+                        * 2: mixed mode, single operand: the inputs are hi + lo tensors but C0 / C1 / K count LOGICAL channels; the fused prologue
+                        *    (required) rounds act((hi + lo) * a + b) once to f16: plain weights, plain K loop.  Configs 6 / 7 only. */
   /* fused epilogue extras of the weights-direct GEMM (pmi_gemm_wd_eligible() == 1, 16-bit output, no split-K), the MLP of the CLIP tower
    * (ruclip/model.py:27-58) and its input gradient: */
   void* D2;            /* optional second output [M][ldd] 16-bit: the PRE-activation value (c_fc output kept for the backward pass) */
@@ -120,6 +124,9 @@ int pmi_softmax_f32(float* S, int rows, int T, int ld, float scale, pmi_stream_t
 /* fp32 [rows][C] (row pitch ld_in) <-> precise [rows][2C] */
 int pmi_split_from_f32(const float* in, int ld_in, void* out, int64_t rows, int C, pmi_stream_t s);
 int pmi_split_to_f32(const void* in, float* out, int64_t rows, int C, pmi_stream_t s);
+/* plain f16 [rows][C] <-> precise [rows][2C] (to_split 1: low parts zero; 0: hi + lo rounded once): the level boundaries of the mixed mode,
+ * where unet.py:626-654's tensors change between the two storage forms */
+int pmi_split_convert(const void* in, void* out, int64_t rows, int C, int to_split, pmi_stream_t s);
 
 /* ---- GroupNorm (+FiLM, +activation, +2x2 average pool) ---------------------------
  * unet.py:232-252 / nn.py:17-19 (GroupNorm32 -> SiLU, FiLM h*(1+scale)+shift),

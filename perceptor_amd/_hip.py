@@ -70,6 +70,7 @@ _PROTOS = {
     "pmi_softmax_f32": ([_P, _I, _I, _I, _F, _P],),
     "pmi_split_from_f32": ([_P, _I, _P, _L, _I, _P],),
     "pmi_split_to_f32": ([_P, _P, _L, _I, _P],),
+    "pmi_split_convert": ([_P, _P, _L, _I, _I, _P],),
     "pmi_gn_stats": ([_P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],),
     "pmi_gn_finalize": ([_P, _I, _I, _P, _I, _I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _F, _P],),
     "pmi_gn_apply_pool_skip": ([_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],),

@@ -438,16 +438,19 @@ extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
     return 8;
   if ((Cin % 64) || (a->C0 % 64) || (a->W % 32) || (a->H % 8)) return -1;
   if (a->split_out || a->split_in) {
-    // precise mode (hi + lo f16 pairs): the weights-direct kernel's 16x16x32 configs only -- its input is an ordinary K dimension of 2C
-    // physical channels against duplicated weights, its split epilogue writes [C/32][hi | lo]; no fused prologue / statistics there
-    if (!a->Bf || !g_wd || !g_wd_mf16 || a->split_out != 32 || !a->split_in || a->out_f32 || (a->R && a->res_f32) || a->pro_a || a->stats ||
-        (a->N % 128))
-      return -1;
+    // precise / mixed mode (hi + lo f16 pairs): the weights-direct kernel's 16x16x32 configs only.  Without a prologue a split input is an
+    // ordinary K dimension of 2C physical channels against duplicated weights; with one the kernel stages (hi, lo) pairs (split_in 1: doubled
+    // operand, 2: single operand over the logical channels).  The split epilogue writes [C/32][hi | lo] and takes the output statistics.
+    if (!a->Bf || !g_wd || !g_wd_mf16 || a->split_out != 32 || a->out_f32 || (a->R && a->res_f32) || (a->N % 128) || a->dtype == PMI_DT_BF16) return -1;
+    if (a->split_in == 2 && !a->pro_a) return -1;
+    if (a->pro_a && (a->pro_act != PMI_ACT_SILU || !a->split_in)) return -1;
+    const int cin_l = a->split_in == 1 ? Cin / 2 : Cin;     // the prologue's coefficient table counts logical channels
     const int t8s = a->M / (a->H * a->W) * (a->H / 8) * (a->W / 32);
-    if (g_force_cfg == 6 || g_force_cfg == 7) return ((a->N % 256) == 0 || g_force_cfg == 7) ? g_force_cfg : -1;
+    const bool ok6 = (a->N % 256) == 0 && (!a->pro_a || cin_l <= 2048), ok7 = !a->pro_a || cin_l <= 1024;
+    if (g_force_cfg == 6 || g_force_cfg == 7) return (g_force_cfg == 6 ? ok6 : ok7) ? g_force_cfg : -1;
     if (g_force_cfg >= 0) return -1;
-    if ((a->N % 256) == 0 && t8s * (a->N / 256) >= 192) return 6;
-    if (g_wd128 && t8s * (a->N / 128) >= 128) return 7;
+    if (ok6 && t8s * (a->N / 256) >= 192) return 6;
+    if (g_wd128 && ok7 && t8s * (a->N / 128) >= 128) return 7;
     return -1;
   }
   // config 3: at most 32 output channels (the UNet's last conv, 128 -> 6): one MFMA block column per wave

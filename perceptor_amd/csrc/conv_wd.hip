@@ -49,12 +49,21 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // SMALLC (config 8): at most 32 input channels (the UNets' first convolution: 3 image channels padded to 8, SD's 4 latent channels, yfcc's 19 -> 24):
 // the whole K = 9 taps x Cin fits a handful of 32-deep MFMA steps, so the patch (10 x 34 pixels x Cin) is staged once, the wave's weights sit in
 // registers, and the B fragments are gathered per tap straight from the patch; tile, accumulator layout and epilogue are config 7's.
-template <typename T, int PRO, bool MF16, int NWN = 8, int CK = 64, bool SPL = false, bool SK = false, bool SMALLC = false>
+// SIN (mixed mode, split_in): the sources are hi + lo tensors ([C/32][hi 32 | lo 32] per pixel) AND a prologue is fused, which needs the
+// VALUE hi + lo of a channel: a staging unit is then the pair of 16-byte pieces holding the high and the low parts of 8 logical channels.
+//   SIN = 2: single operand: act((hi + lo) * a + b) is rounded ONCE to f16 -- the K loop is the plain kernel's over the logical channels.
+//   SIN = 1: doubled operand: the result is split again, y = yh + yl, and a chunk's K is [yh of CK/2 logical channels | their yl] against
+//            weights duplicated in the same pattern (W*yh + W*yl in fp32: an fp32-grade product at twice the MFMA work).
+// (PRO = 0 over a split input needs neither: its 2C physical channels are an ordinary K dimension, SIN = 0.)
+template <typename T, int PRO, bool MF16, int NWN = 8, int CK = 64, bool SPL = false, bool SK = false, bool SMALLC = false, int SIN = 0>
 __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm_args a) {
+  static_assert(SIN == 0 || (PRO != 0 && MF16 && !SK && !SMALLC && std::is_same<T, F16>::value), "split-input staging: fused prologue, f16, 16x16x32 tiles");
   constexpr int NW = NWN, NT = NW * 64;
   constexpr int KS = MF16 ? CK / 32 : CK / 16;         // k-steps (one MFMA deep) per chunk
   constexpr int PP = 10 * PW;                          // patch pixels
-  constexpr int CPR = CK / 8;                          // 16-byte chunks per patch pixel
+  constexpr int CPR = SIN == 1 ? CK / 16 : CK / 8;     // staging units per patch pixel: 16-byte pieces, or (hi, lo) pairs of them
+  constexpr int LCK = SIN == 1 ? CK / 2 : CK;          // logical input channels per chunk
+  constexpr int NLD = SIN ? 2 : 1;                     // 16-byte loads per staging unit
   constexpr int NG = MF16 ? 3 * KS * 2 : 3 * KS;       // groups per chunk: 3 dx x k-steps (x 2 half-rows with 16x16x32); 12 at CK = 64
   constexpr int WGC = 3 * KS;                          // weight groups per chunk (3 dy fragments of 1 KB each, x 2 channel blocks with MF16)
   constexpr int NWF = MF16 ? 6 : 3;                    // fragments per weight group
@@ -64,7 +73,8 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
   constexpr int PATCH_BYTES = (NPI * NT / CPR) * ROW;  // padded to whole staging passes: no bounds test on the LDS writes
   constexpr int BN = NWN * 32, NPX = 256;
   constexpr int SROW = BN * 2 + 16;                    // epilogue staging row: BN 16-bit channels + 16 B pad
-  constexpr int EPI_BYTES = NPX * SROW + NW * BN * 8 + BN * 4;
+  constexpr int FROW = (BN / 2) * 4 + 16;              // split epilogue: fp32 image of HALF the tile's channels per pass, 16 B pad
+  constexpr int EPI_BYTES = SPL ? NPX * FROW + NW * (BN / 2) * 8 + BN * 4 : NPX * SROW + NW * BN * 8 + BN * 4;
   constexpr int MAXCIN = NWN == 8 ? 2048 : 1024;       // fused-prologue coefficient table: a[Cin], b[Cin] fp32 of this image
   constexpr int COEF_BYTES = PRO ? 2 * MAXCIN * 4 : 0;
   constexpr int PPIX_BYTES = NPI * NT * 4;             // source pixel of every staged piece of this thread (kept out of the registers)
@@ -107,12 +117,15 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
   // with output tiles alone: 32x32 at batch 8); bias / activation / residual then happen in splitk_reduce_kernel (igemm.hip)
   const int nsplit = SK ? a.splitk : 1;
   const int cb0 = SK ? (nchunks / nsplit) * blockIdx.z : 0, ce = SK ? cb0 + nchunks / nsplit : nchunks, nloc = ce - cb0;
-  const int sc = tid % CPR;                            // 16-byte chunk (8 channels) of a patch pixel this thread stages
+  const int sc = tid % CPR;                            // staging unit (8 channels) of a patch pixel this thread stages
   const int64_t img_px = (int64_t)a.Hin * a.Win;
   const u16* const A0i = (const u16*)a.A0 + (int64_t)img * img_px * a.lda0;
   const u16* const A1i = a.A1 ? (const u16*)a.A1 + (int64_t)img * img_px * a.lda1 : A0i;
-  const int64_t bytes0 = ((img_px - 1) * a.lda0 + a.C0) * 2;
-  const int64_t bytes1 = a.A1 ? ((img_px - 1) * a.lda1 + a.C1) * 2 : 0;
+  // a.C0 / a.C1 count what the K index counts: logical channels for SIN = 2 (rows hold twice as many values), physical ones otherwise
+  const int64_t bytes0 = ((img_px - 1) * a.lda0 + (SIN == 2 ? 2 * a.C0 : a.C0)) * 2;
+  const int64_t bytes1 = a.A1 ? ((img_px - 1) * a.lda1 + (SIN == 2 ? 2 * a.C1 : a.C1)) * 2 : 0;
+  const int C0l = SIN == 1 ? a.C0 >> 1 : a.C0;          // logical channels of the first source
+  const int CinL = SIN == 1 ? Cin >> 1 : Cin;           // logical input channels (the prologue's coefficient count)
   // this wave's weight stream: [chunk][dx][step][dy](x [16-channel block])[lane][8] 16-bit, contiguous in loop order
   const int64_t wslab = (int64_t)nchunks * WGC * GB;
   const bool wave_live = n0 + wn * 32 < a.N;           // wave-uniform; a dead wave's weight resource is empty (every load returns zeros)
@@ -132,31 +145,66 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
   // (the coefficient table is filled in the prologue below, AFTER the first patch loads are in flight: one memory latency, not two)
 
   // source of chunk `chunk`: which tensor, row pitch, channel offset (wave-uniform: C0 is a multiple of CK)
-  auto load_piece = [&](int chunk, int pix, bool live) -> uint4 {        // !live: out-of-range offset, zeros, no traffic, no branch
-    const int cbase = chunk * CK;
-    const bool second = cbase >= a.C0;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(second ? A1i : A0i, second ? bytes1 : bytes0);
-    const uint32_t ld2 = (uint32_t)(second ? a.lda1 : a.lda0) * 2u;
-    const uint32_t so = (uint32_t)(cbase - (second ? a.C0 : 0)) * 2u;
-    const uint32_t vo = (pix >= 0 && live) ? (uint32_t)pix * ld2 + (uint32_t)sc * 16u : PMI_BUF_OOB;
-    return buf_load16(rs, vo, so);
+  struct Piece { uint4 v[NLD]; };
+  auto load_piece = [&](int chunk, int pix, bool live) -> Piece {       // !live: out-of-range offset, zeros, no traffic, no branch
+    Piece r;
+    if constexpr (SIN == 0) {
+      const int cbase = chunk * CK;
+      const bool second = cbase >= a.C0;
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(second ? A1i : A0i, second ? bytes1 : bytes0);
+      const uint32_t ld2 = (uint32_t)(second ? a.lda1 : a.lda0) * 2u;
+      const uint32_t so = (uint32_t)(cbase - (second ? a.C0 : 0)) * 2u;
+      const uint32_t vo = (pix >= 0 && live) ? (uint32_t)pix * ld2 + (uint32_t)sc * 16u : PMI_BUF_OOB;
+      r.v[0] = buf_load16(rs, vo, so);
+    } else {
+      // logical channels [cl, cl + LCK) of one source (cl a multiple of LCK = 16, 32 or 64: a unit's 8 channels never straddle a 32-group
+      // unless LCK = 64, where units 4..7 sit in the next group -- split_off of the per-thread part alone covers both cases)
+      const int cbase = chunk * LCK;
+      const bool second = cbase >= C0l;
+      const __amdgpu_buffer_rsrc_t rs = make_rsrc(second ? A1i : A0i, second ? bytes1 : bytes0);
+      const uint32_t ld2 = (uint32_t)(second ? a.lda1 : a.lda0) * 2u;
+      const int cl = cbase - (second ? C0l : 0);
+      const uint32_t so = (uint32_t)split_off(cl, 32) * 2u;
+      const uint32_t vo = (pix >= 0 && live) ? (uint32_t)pix * ld2 + (uint32_t)split_off(sc * 8, 32) * 2u : PMI_BUF_OOB;
+      r.v[0] = buf_load16(rs, vo, so);
+      r.v[1] = buf_load16(rs, vo + 64u, so);            // the low parts: 32 elements behind the high parts (an out-of-range offset stays out of range)
+    }
+    return r;
   };
   auto read_coef = [&](int chunk, float* ga, float* gb) {
-    const float* ca = coef + chunk * CK + sc * 8;
+    const float* ca = coef + chunk * LCK + sc * 8;
     *(float4*)ga = *(const float4*)ca; *(float4*)(ga + 4) = *(const float4*)(ca + 4);
     *(float4*)gb = *(const float4*)(ca + MAXCIN); *(float4*)(gb + 4) = *(const float4*)(ca + MAXCIN + 4);
   };
-  auto store_piece = [&](char* pbuf, int i, uint4 v, int pix, const float* ga, const float* gb) {
+  auto store_piece = [&](char* pbuf, int i, Piece pc, int pix, const float* ga, const float* gb) {
+    uint4 v = pc.v[0];
+    char* const dst = pbuf + (tid / CPR) * ROW + sc * 16 + i * (NT / CPR) * ROW;
     if (PRO) {                                          // GroupNorm-apply + activation; zero padding stays zero
       float f[8];
       unpack8<T>(v, f);
+      if constexpr (SIN != 0) {
+        float lo[8];
+        unpack8<T>(pc.v[1], lo);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += lo[e];
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = act_apply(f[e] * ga[e] + gb[e], PRO - 1);
-      v = pack8<T>(f);
       const uint32_t keep = pix >= 0 ? 0xffffffffu : 0u;
+      v = pack8<T>(f);
+      if constexpr (SIN == 1) {                         // second operand half: what the 16-bit value lost
+        float lo[8];
+        float hf[8];
+        unpack8<T>(v, hf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) lo[e] = f[e] - hf[e];
+        uint4 vl = pack8<T>(lo);
+        vl.x &= keep; vl.y &= keep; vl.z &= keep; vl.w &= keep;
+        *(uint4*)(dst + CK) = vl;                       // [yh of the chunk's CK / 2 channels | their yl]: CK bytes apart
+      }
       v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
     }
-    *(uint4*)(pbuf + (tid / CPR) * ROW + sc * 16 + i * (NT / CPR) * ROW) = v;
+    *(uint4*)dst = v;
   };
 
   f32x16 acc[MF16 ? 1 : 8];                             // 32x32x16: [row]
@@ -230,14 +278,14 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
   load_wg(0, cb0 * WGC);
   if (!MF16) load_wg(1, cb0 * WGC + 1);
   {
-    uint4 p0[NPI];
+    Piece p0[NPI];
     float ga[8], gb[8];
 #pragma unroll
     for (int i = 0; i < NPI; ++i) p0[i] = load_piece(cb0, ppix_s[i * NT + tid], true);    // (a thread reads only its own table entries)
     if (PRO) {
-      for (int c = tid; c < Cin; c += NT) {
-        coef[c] = a.pro_a[(int64_t)img * Cin + c];
-        coef[MAXCIN + c] = a.pro_b[(int64_t)img * Cin + c];
+      for (int c = tid; c < CinL; c += NT) {
+        coef[c] = a.pro_a[(int64_t)img * CinL + c];
+        coef[MAXCIN + c] = a.pro_b[(int64_t)img * CinL + c];
       }
       __syncthreads();
       read_coef(cb0, ga, gb);
@@ -269,7 +317,7 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
   // carried staging state: the piece waiting for its store slot, its source pixel, and the source pixel of the next load.
   // Table reads (ppix_s, coef) are issued a phase before their use, so their waits are counted lgkmcnt(N), not drains.
   int pixc = ppix_s[0 * NT + tid];
-  uint4 pr = load_piece(nloc > 1 ? cb0 + 1 : cb0, pixc, nloc > 1);    // piece 0 of the second chunk's patch
+  Piece pr = load_piece(nloc > 1 ? cb0 + 1 : cb0, pixc, nloc > 1);    // piece 0 of the second chunk's patch
   int pixn = ppix_s[1 * NT + tid];
   // With an odd number of weight groups per chunk (CK = 32: 3) the two-slot weight ring changes phase from chunk to chunk; the ring slot
   // must be a compile-time register index, so the chunk body is unrolled over both phases and the loop advances two chunks at a time
@@ -296,7 +344,7 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
       const bool load_slot = (g + 1 == NG) || (g % SG == SG - 1 && lp < NPI);
       float ga[8], gb[8];
       if (PRO && store_slot) read_coef(cn, ga, gb);
-      uint4 prn = pr;
+      Piece prn = pr;
       int pixl = pixc;
       if (load_slot) { prn = load_piece(g + 1 == NG ? cn2 : cn, pixn, g + 1 == NG ? more2 : more); pixl = pixn; }
       __builtin_amdgcn_sched_barrier(0);   // keep the global loads in front of the MFMAs (the scheduler sinks them to their use)
@@ -377,49 +425,124 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
     }
   }
   if constexpr (SPL) {
-    // ---- precise-mode epilogue: straight from the accumulators.  A lane holds 4 consecutive channels of a pixel: 8 bytes of high parts
-    // and 8 bytes of low parts, the four quarter-waves of a 16-channel block complete two 32-byte runs per pixel.  No statistics here
-    // (pmi_igemm_stats_rows reports none for split outputs: the next GroupNorm runs its own pass), a split residual is added in fp32.
-    static_assert(MF16 && PRO == 0, "precise mode: 16x16x32 tiles without a fused prologue");
-    const int G = a.split_out;                           // 32 (Cout is a multiple of 128)
-    const float* const nbp = a.nbias ? a.nbias + (int64_t)img * (a.ldnb ? a.ldnb : a.N) : nullptr;
-    act_switch(a.act, [&](auto act_c) __attribute__((always_inline)) {
-      constexpr int ACT = decltype(act_c)::value;
+    // ---- split-output epilogue (precise / mixed mode): [C/32][hi 32 | lo 32] f16 pairs per pixel.  The tile's values go through LDS as
+    // fp32 (the same 4 bytes per element as the pair) in TWO passes of BN / 2 channels -- the waves owning them write their accumulators
+    // (+ bias, activation), then every wave streams pixel rows out: a lane reads 8 channels (32 B), adds the residual's hi + lo (two 16-byte
+    // loads issued before the pass), accumulates the output statistics, splits and writes 16 B of high parts and 16 B of low parts; the 4
+    // lanes of a 32-channel group complete a 128-byte line with two back-to-back stores.  (Round 2 wrote 8-byte pieces straight from the
+    // accumulators: 512x512 layers ran at 1.4-1.7 TB/s of algorithmic traffic, latency-bound on partial lines.)
+    static_assert(MF16, "split outputs: 16x16x32 tiles");
+    constexpr int HB = BN / 2, HW_ = NW / 2;             // channels, owning waves per pass
+    constexpr int LPR = HB / 8;                          // lanes per pixel row of a pass (16 bytes of hi + 16 of lo each): 16 / 8
+    constexpr int PPI = 64 / LPR;                        // pixels per store instruction: 4 / 8
+    constexpr int PXW = NPX / NW;                        // pixels written out by a wave: 32 / 64
+    constexpr int NWI = PXW / PPI;                       // iterations per wave and pass (8)
+    char* const img_ = smem;
+    float* const stat = (float*)(smem + NPX * FROW);     // [NW][HB][2] (sum, sumsq) partials per write-out wave, summed in a fixed order
+    float* const bsm = stat + NW * HB * 2;               // [BN] bias + per-sample bias
+    for (int c = tid; c < BN; c += NT) {
+      const int n = n0 + c;
+      float b = a.bias ? a.bias[n] : 0.f;
+      if (a.nbias) b += a.nbias[(int64_t)img * (a.ldnb ? a.ldnb : a.N) + n];
+      bsm[c] = b;
+    }
+    __syncthreads();                                     // bias visible; the main loop's last barrier already freed the patch buffers
+    const int q = lane % LPR, psub = lane / LPR, cl0 = q * 8;
+    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+    constexpr int RD = 4;                                // residual prefetch depth (iterations): 8 registers each, the accumulators are still live
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        const int n = n0 + wn * 32 + cb * 16 + 4 * (lane >> 4);
-        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias) b = *(const float4*)(a.bias + n);
-        if (nbp) { const float4 q = *(const float4*)(nbp + n); b.x += q.x; b.y += q.y; b.z += q.z; b.w += q.w; }
-        const int po = split_off(n, G);                  // offset of the high parts inside a pixel row; low parts at + G
+    for (int hp = 0; hp < 2; ++hp) {
+      const int nq = n0 + hp * HB + cl0;                 // this lane's 8 logical output channels (inside one 32-group)
+      const int po = split_off(nq, 32);                  // their high parts inside a pixel row; low parts 32 elements further
+      uint4 rh[RD], rl[RD];
+      auto load_res = [&](int t) {
+        const int p = wid * PXW + t * PPI + psub;
+        const int y = y0 + (p >> 5), x = x0 + (p & 31);
+        const int64_t rr = a.res_up ? (((int64_t)img * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.ldr
+                                    : (((int64_t)img * a.H + y) * a.W + x) * a.ldr;
+        const u32x4_ h_ = __builtin_nontemporal_load((const u32x4_*)((const u16*)a.R + rr + po));
+        const u32x4_ l_ = __builtin_nontemporal_load((const u32x4_*)((const u16*)a.R + rr + po + 32));
+        rh[t % RD] = make_uint4(h_.x, h_.y, h_.z, h_.w); rl[t % RD] = make_uint4(l_.x, l_.y, l_.z, l_.w);
+      };
+      if (a.R) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int sx = 0; sx < 2; ++sx) {
-            const f32x4 c = acc4[i][sx][cb];
-            float v[4] = {c[0] * a.alpha + b.x, c[1] * a.alpha + b.y, c[2] * a.alpha + b.z, c[3] * a.alpha + b.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], ACT);
-            const int y = y0 + i, x = x0 + sx * 16 + (lane & 15);
-            if (a.R) {
-              const int64_t rr = a.res_up ? (((int64_t)img * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.ldr
-                                          : (((int64_t)img * a.H + y) * a.W + x) * a.ldr;
-              const uint2 rh = *(const uint2*)((const u16*)a.R + rr + po), rl = *(const uint2*)((const u16*)a.R + rr + po + G);
-              v[0] += F16::to_f((u16)(rh.x & 0xffff)) + F16::to_f((u16)(rl.x & 0xffff));
-              v[1] += F16::to_f((u16)(rh.x >> 16)) + F16::to_f((u16)(rl.x >> 16));
-              v[2] += F16::to_f((u16)(rh.y & 0xffff)) + F16::to_f((u16)(rl.y & 0xffff));
-              v[3] += F16::to_f((u16)(rh.y >> 16)) + F16::to_f((u16)(rl.y >> 16));
-            }
-            u16 h[4];
-            float l[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { h[e] = F16::from_f(v[e]); l[e] = v[e] - F16::to_f(h[e]); }
-            u16* const o = (u16*)a.D + (((int64_t)img * a.H + y) * a.W + x) * a.ldd + po;
-            *(uint2*)o = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-            *(uint2*)(o + G) = pack4<F16>(l[0], l[1], l[2], l[3]);
-          }
+        for (int t = 0; t < RD; ++t) load_res(t);        // the first residual loads fly while the accumulators are staged
       }
-    });
+      if (wn / HW_ == hp) {                              // wave-uniform: this wave's 32 channels belong to the pass
+        const int wl = wn - hp * HW_;
+        act_switch(a.act, [&](auto act_c) __attribute__((always_inline)) {
+          constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            const int cl = wl * 32 + cb * 16 + 4 * (lane >> 4);
+            const float4 b = *(const float4*)(bsm + hp * HB + cl);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+              for (int sx = 0; sx < 2; ++sx) {
+                const f32x4 c = acc4[i][sx][cb];
+                float4 v = make_float4(c[0] * a.alpha + b.x, c[1] * a.alpha + b.y, c[2] * a.alpha + b.z, c[3] * a.alpha + b.w);
+                v.x = act_apply(v.x, ACT); v.y = act_apply(v.y, ACT); v.z = act_apply(v.z, ACT); v.w = act_apply(v.w, ACT);
+                *(float4*)(img_ + (i * 32 + sx * 16 + (lane & 15)) * FROW + cl * 4) = v;
+              }
+          }
+        });
+      }
+      __syncthreads();
+      float cs[16];                                      // [0..7] sums, [8..15] sums of squares of this lane's 8 channels
+#pragma unroll
+      for (int e = 0; e < 16; ++e) cs[e] = 0.f;
+#pragma unroll
+      for (int t = 0; t < NWI; ++t) {
+        const int p = wid * PXW + t * PPI + psub;
+        float f[8];
+        *(float4*)f = *(const float4*)(img_ + p * FROW + cl0 * 4);
+        *(float4*)(f + 4) = *(const float4*)(img_ + p * FROW + cl0 * 4 + 16);
+        if (a.R) {
+          float r0[8], r1[8];
+          unpack8<F16>(rh[t % RD], r0);
+          unpack8<F16>(rl[t % RD], r1);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] += r0[e] + r1[e];
+          if (t + RD < NWI) load_res(t + RD);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { cs[e] += f[e]; cs[8 + e] += f[e] * f[e]; }
+        const uint4 vh = pack8<F16>(f);
+        float hf[8], lo[8];
+        unpack8<F16>(vh, hf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) lo[e] = f[e] - hf[e];
+        const uint4 vl = pack8<F16>(lo);
+        const int y = y0 + (p >> 5), x = x0 + (p & 31);
+        u16* const o = (u16*)a.D + (((int64_t)img * a.H + y) * a.W + x) * a.ldd + po;
+        __builtin_nontemporal_store((u32x4_){vh.x, vh.y, vh.z, vh.w}, (u32x4_*)o);
+        __builtin_nontemporal_store((u32x4_){vl.x, vl.y, vl.z, vl.w}, (u32x4_*)(o + 32));
+      }
+      if (a.stats) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          cs[e] += __shfl_xor(cs[e], 32);
+          cs[e] += __shfl_xor(cs[e], 16);
+          if (LPR == 8) cs[e] += __shfl_xor(cs[e], 8);
+        }
+        if (lane < LPR) {
+          float* const slot = stat + (wid * HB + cl0) * 2;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { slot[2 * e] = cs[e]; slot[2 * e + 1] = cs[8 + e]; }
+        }
+      }
+      __syncthreads();                                   // every wave is done with the image (next pass overwrites it); statistic slots complete
+      if (a.stats) {
+        float* o = a.stats + (((int64_t)img * a.stats_p + ty * tiles_x + tx) * a.N + n0 + hp * HB) * 2;
+        for (int c = tid; c < 2 * HB; c += NT) {
+          float v = 0.f;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) v += stat[w * 2 * HB + c];
+          o[c] = v;
+        }
+      }
+    }
     STAMP(3);
     return;
   }
@@ -560,16 +683,30 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
 template <typename T, int PRO>
 int launch_p(const pmi_igemm_args& a, hipStream_t s, int cfg) {
   const int nimg = a.M / (a.H * a.W);
-  if constexpr (PRO == 0) {
-    if (a.split_out) {                                 // precise mode (hi + lo output): configs 6 / 7 only
-      if (cfg == 7) hipLaunchKernelGGL((conv3x3_wd_kernel<T, 0, true, 4, 32, true>), dim3(nimg * (a.H / 8) * (a.W / 32) * (a.N / 128)), dim3(256), 0, s, a);
-      else if (cfg == 6) hipLaunchKernelGGL((conv3x3_wd_kernel<T, 0, true, 8, 64, true>), dim3(nimg * (a.H / 8) * (a.W / 32) * (a.N / 256)), dim3(512), 0, s, a);
-      else return PMI_ERR_ARG;
-      PMI_CHECK_LAUNCH();
-      return PMI_OK;
+  if (a.split_out) {                                   // precise / mixed mode (hi + lo output): configs 6 / 7 only, f16 arithmetic
+    const dim3 g7(nimg * (a.H / 8) * (a.W / 32) * (a.N / 128)), g6(nimg * (a.H / 8) * (a.W / 32) * (a.N / 256));
+    if (cfg != 6 && cfg != 7) return PMI_ERR_ARG;
+    if constexpr (PRO == 0) {
+      if (a.split_in == 2) return PMI_ERR_ARG;
+      if (cfg == 7) hipLaunchKernelGGL((conv3x3_wd_kernel<T, 0, true, 4, 32, true>), g7, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((conv3x3_wd_kernel<T, 0, true, 8, 64, true>), g6, dim3(512), 0, s, a);
+    } else if constexpr (PRO == 1 + PMI_ACT_SILU && std::is_same<T, F16>::value) {
+      // fused GroupNorm-apply + SiLU over a split input: the doubled operand (split_in 1) or the single operand (split_in 2)
+      if (a.split_in != 1 && a.split_in != 2) return PMI_ERR_ARG;
+      if (cfg == 7) {
+        if (a.split_in == 1) hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, true, 4, 32, true, false, false, 1>), g7, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, true, 4, 32, true, false, false, 2>), g7, dim3(256), 0, s, a);
+      } else {
+        if (a.split_in == 1) hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, true, 8, 64, true, false, false, 1>), g6, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_wd_kernel<T, PRO, true, 8, 64, true, false, false, 2>), g6, dim3(512), 0, s, a);
+      }
+    } else {
+      return PMI_ERR_ARG;
     }
+    PMI_CHECK_LAUNCH();
+    return PMI_OK;
   }
-  if (a.split_out) return PMI_ERR_ARG;
+  if (a.split_in) return PMI_ERR_ARG;
   if (cfg == 8) {                                      // at most 32 input channels (first convolution): PRO == 0 only
     if constexpr (PRO == 0) {
       hipLaunchKernelGGL((conv3x3_wd_kernel<T, 0, true, 4, 32, false, false, true>), dim3(nimg * (a.H / 8) * (a.W / 32) * ((a.N + 127) / 128)), dim3(256), 0, s, a);

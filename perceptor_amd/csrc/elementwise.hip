@@ -200,6 +200,24 @@ __global__ __launch_bounds__(256) void split_to_f32_kernel(const u16* __restrict
   }
 }
 
+// plain f16 [rows][C] <-> split (hi + lo) [rows][2C]: the level boundaries of the mixed mode (engine/adm_mixed.py).  Towards the plain side the
+// value hi + lo is rounded once; towards the split side the low parts are zero.
+__global__ __launch_bounds__(256) void split_convert_kernel(const u16* __restrict__ in, u16* __restrict__ out, int64_t rows, int C, int to_split) {
+  const int C8 = C >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * C8; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t r = i / C8;
+    float f[8];
+    if (to_split) {
+      load8<F16>(in + r * C, c8 * 8, C, f);
+      store8<F16X2>(out + r * 2 * C, c8 * 8, C, f);
+    } else {
+      load8<F16X2>(in + r * 2 * C, c8 * 8, C, f);
+      store8<F16>(out + r * C, c8 * 8, C, f);
+    }
+  }
+}
+
 __global__ void fourier_features_kernel(const float* __restrict__ t, const float* __restrict__ w, float* __restrict__ out, int N, int half) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * half) return;
@@ -347,6 +365,12 @@ extern "C" int pmi_timestep_embedding(const float* t, void* out, int N, int dim,
   if (!t || !out || N <= 0 || dim <= 0 || (dim & 1)) return PMI_ERR_ARG;
   dim3 grid((N * dim / 2 + 255) / 256), block(256);
   BY_DTYPE(timestep_embedding_kernel, t, (u16*)out, N, dim, max_period);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_split_convert(const void* in, void* out, int64_t rows, int C, int to_split, pmi_stream_t s) {
+  if (!in || !out || rows <= 0 || C <= 0 || (C & 7) || (C > 32 && (C & 31))) return PMI_ERR_ARG;
+  hipLaunchKernelGGL(split_convert_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, ST, (const u16*)in, (u16*)out, rows, C, to_split);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }

@@ -90,11 +90,14 @@ class PackedLinear:
                 return torch.cat(parts, dim=2)
             w_hi = packed.to(torch.float16).float()
             w_lo = packed - w_hi                     # what f16 cannot hold of fp32 weights (zero for fp16 checkpoints / the synthetic weights)
+            self._w1, self._sources = w_hi, list(sources or [self.cin_l])     # un-duplicated weights: other duplication patterns are built on demand
             packed = dup(w_hi)
             self.cin_p = 2 * self.cin_l              # channels of the (physical) input tensors
-            # f16 holds the weights to within the mode's own precision (~2^-22 of the largest weight; tiny values below the f16
-            # subnormal grid lose < 6e-8 absolute): nothing to add.  Otherwise the low part becomes a second K block.
-            if float(w_lo.abs().max()) > 2.0 ** -22 * float(packed.abs().max()):
+            # f16 holds the weights to within the mode's own precision: nothing to add.  Otherwise the low part becomes a second K block.
+            # The measure is the low part's share of the weight NORM (what reaches a sum over K), not its largest element: bf16-exact or
+            # fp16-checkpoint weights of a long-K layer have a few values under the f16 subnormal grid (< 2^-14: they lose < 3e-8 absolute,
+            # ~4e-8 of the norm) -- the max-element test of round 2 doubled K for every such layer (4x the MFMA work, for nothing).
+            if float(w_lo.norm()) > 2.0 ** -22 * float(w_hi.norm()):
                 if sources is not None:
                     import warnings
                     warnings.warn("precise mode: fp32 weights of a two-source (concat) convolution are rounded to f16")
@@ -130,13 +133,25 @@ class PackedLinear:
             self._frag["gemm"] = w.permute(0, 3, 4, 1, 5, 2, 6).contiguous()
         return self._frag["gemm"]
 
-    def frag16(self, ck: int) -> torch.Tensor:
+    def frag16(self, ck: int, dup_g: int = 0) -> torch.Tensor:
         """Fragment order for the 16x16x32 MFMA form of the weights-direct kernel:
-        [N/32][Cin/ck][dx][ck/32][dy][16-channel block][lane = 16*(k quarter) + channel][8 k]."""
-        key = ("mf16", ck)
+        [N/32][Cin/ck][dx][ck/32][dy][16-channel block][lane = 16*(k quarter) + channel][8 k].
+        dup_g (split weights only): the K order [W of dup_g logical channels | the same again] per group -- the kernel's fused prologue
+        over a split input stages a chunk as [yh of ck/2 channels | their yl] (csrc/conv_wd.hip, SIN = 1), so dup_g = ck / 2; the default
+        is the tensors' own memory order, groups of 32."""
+        key = ("mf16", ck, dup_g)
         if key not in self._frag:
             assert self.taps == 9 and self.n_p % 32 == 0 and self.cin_p % ck == 0
-            w = self.w.view(self.n_p // 32, 2, 16, 3, 3, self.cin_p // ck, ck // 32, 4, 8)   # nb, cb, r16, dy, dx, chunk, k32, q4, j
+            src = self.w
+            if dup_g and dup_g != 32:
+                assert self.split and not self.self_concat and all(cs % dup_g == 0 for cs in self._sources)
+                parts, o = [], 0
+                for cs in self._sources:
+                    blk = self._w1[:, :, o:o + cs].reshape(self.n_p, 9, cs // dup_g, 1, dup_g).expand(-1, -1, -1, 2, -1)
+                    parts.append(blk.reshape(self.n_p, 9, 2 * cs))
+                    o += cs
+                src = torch.cat(parts, dim=2).reshape(self.n_p, -1).to(device=self.w.device, dtype=self.w.dtype).contiguous()
+            w = src.view(self.n_p // 32, 2, 16, 3, 3, self.cin_p // ck, ck // 32, 4, 8)   # nb, cb, r16, dy, dx, chunk, k32, q4, j
             self._frag[key] = w.permute(0, 5, 4, 6, 3, 1, 7, 2, 8).contiguous()
         return self._frag[key]
 
@@ -163,11 +178,99 @@ class PackedLinear:
         return self._frag[ck]
 
 
+class MixedLinear:
+    """Both packings of one 3x3 convolution for the mixed mode (engine/adm_mixed.py), built on first use: `single` = plain f16 weights over the
+    logical channels (the operand act(GroupNorm(hi + lo)) is rounded once to f16), `dbl` = weights duplicated along K for the hi + lo operand
+    (also what the generic fallback path takes)."""
+
+    def __init__(self, weight, bias, device, sources=None, cin_pad=None):
+        self._args = (weight, bias, device, sources, cin_pad)
+        self._single = self._dbl = None
+
+    @property
+    def single(self) -> PackedLinear:
+        if self._single is None:
+            w, b, dev, _, cp = self._args
+            self._single = PackedLinear(w, b, _hip.DT_F16, dev, cin_pad=cp)
+        return self._single
+
+    @property
+    def dbl(self) -> PackedLinear:
+        if self._dbl is None:
+            w, b, dev, src, cp = self._args
+            self._dbl = PackedLinear(w, b, DT_F16X2, dev, cin_pad=cp, sources=src)
+        return self._dbl
+
+
+def split_convert(x: torch.Tensor, to_split: bool) -> torch.Tensor:
+    """plain f16 [..., C] <-> split (hi + lo) [..., 2C] (pmi_split_convert): the level boundaries of the mixed mode."""
+    c = x.shape[-1] if to_split else x.shape[-1] // 2
+    y = _empty(x.shape[:-1] + ((2 * c) if to_split else c,), torch.float16, x.device)
+    call("pmi_split_convert", ptr(x), ptr(y), x.numel() // x.shape[-1], c, int(to_split))
+    return y
+
+
+MIXED_TRACE = None      # tools / tests: list collecting (route, operand, shape) of every conv3x3_mixed call
+
+
+def conv3x3_mixed(x: torch.Tensor, mlin: MixedLinear, *, operand: str, prologue, x1: Optional[torch.Tensor] = None, up: bool = False,
+                  residual: Optional[torch.Tensor] = None, res_up: bool = False, nbias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Stride-1 3x3 convolution of the mixed mode: x (and x1: skip-concat) are split tensors [N, H, W, 2C]; prologue = (coef_a, coef_b, act) is
+    the fused GroupNorm-apply + SiLU of the input; operand "single": the activated value is rounded once to f16 (K = 9 Cin), "dbl": it is
+    kept as hi + lo (K = 18 Cin, fp32-grade product).  Split output [N, H, W, 2 Cout] with fused statistics; split residual.
+    Shapes the weights-direct kernel does not take fall back to apply pass + generic split convolution (always the doubled operand)."""
+    assert operand in ("single", "dbl")
+    n, hin, win, _ = x.shape
+    h, w = (hin * 2, win * 2) if up else (hin, win)
+    ca, cb, pact = prologue
+    lin = mlin.single if operand == "single" else mlin.dbl
+    a = IgemmArgs()
+    div = 2 if operand == "single" else 1                  # single: C0 / C1 / K count logical channels
+    c0, c1 = x.shape[-1] // div, (x1.shape[-1] // div if x1 is not None else 0)
+    a.H, a.W, a.Hin, a.Win, a.hw = h, w, hin, win, h * w
+    m = n * h * w
+    a.M, a.N, a.K, a.C0, a.C1 = m, lin.n_p, lin.K, c0, c1
+    a.lda0, a.lda1 = x.stride(-2), (x1.stride(-2) if x1 is not None else 0)
+    a.taps, a.stride, a.up, a.res_up, a.act, a.alpha = 9, 1, int(up), int(res_up), ACT_NONE, 1.0
+    a.batch, a.batch_inner, a.dtype = 1, 1, DT_F16X2
+    a.split_in, a.split_out = (2 if operand == "single" else 1), 32
+    a.A0, a.A1, a.B, a.bias, a.nbias, a.R = ptr(x), ptr(x1), ptr(lin.w), ptr(lin.b), ptr(nbias), ptr(residual)
+    a.ldb, a.ldr, a.ldnb = lin.K, (residual.stride(-2) if residual is not None else 0), (nbias.stride(0) if nbias is not None else 0)
+    a.pro_a, a.pro_b, a.pro_act, a.Bf = 1, 1, pact, 1      # markers for the config query
+    cfg = _hip.lib().pmi_conv3x3_halo_config(C.byref(a)) if (lin.n_p % 128 == 0 and lin.K == 9 * (c0 + c1) and WD_ENABLED and HALO_ENABLED) else -1
+    if MIXED_TRACE is not None:
+        MIXED_TRACE.append(("wd" if cfg >= 6 else "fallback", operand, (n, h, w, c0 + c1, lin.cout)))
+    if cfg < 6:
+        d = mlin.dbl
+        return igemm(x, d, a1=x1, up=up, residual=residual, res_up=res_up, nbias=nbias, prologue=prologue, want_stats=True)
+    ck = 64 if cfg == 6 else 32
+    a.Bf = ptr(lin.frag16(ck) if operand == "single" else lin.frag16(ck, dup_g=ck // 2))
+    a.pro_a, a.pro_b, a.pro_act = ptr(ca), ptr(cb), pact
+    out = _empty((n, h, w, 2 * lin.n_p), torch.float16, x.device)
+    a.D, a.ldd = ptr(out), out.stride(-2)
+    rows = _hip.lib().pmi_igemm_stats_rows(C.byref(a))
+    if rows > 0:
+        st = _empty((n, rows, lin.n_p, 2), torch.float32, x.device)
+        a.stats, a.stats_p = ptr(st), rows
+        out._pmi_stats = (st, rows)
+    if KERNEL_EVENTS is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call("pmi_igemm", C.byref(a))
+        e1.record()
+        nbytes = (x.numel() + (x1.numel() if x1 is not None else 0)) * 2 + lin.w.numel() * 2 + out.numel() * 2 + (residual.numel() * 2 if residual is not None else 0)
+        KERNEL_EVENTS.append((e0, e1, 2.0 * m * lin.cout * lin.cin * 9, float(nbytes), f"{h}x{w} {c0}+{c1}->{lin.cout} cfg{cfg} mixed-{operand}"))
+        return out
+    call("pmi_igemm", C.byref(a))
+    return out
+
+
 def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
           act: int = ACT_NONE, up: bool = False, stride: int = 1, res_up: bool = False, nbias: Optional[torch.Tensor] = None,
           out_f32: bool = False, out: Optional[torch.Tensor] = None, alpha: float = 1.0, prologue=None,
           want_stats: bool = False, hw: Optional[int] = None, pre_out: Optional[torch.Tensor] = None,
-          act_grad_of: Optional[torch.Tensor] = None, act_grad: int = ACT_NONE, defer_reduce: bool = False) -> torch.Tensor:
+          act_grad_of: Optional[torch.Tensor] = None, act_grad: int = ACT_NONE, defer_reduce: bool = False,
+          split_out: bool = False) -> torch.Tensor:
     """Convolution (a0 is [N,H,W,C]) or linear (a0 is [M,C]) through pmi_igemm.
 
     prologue = (coef_a [N,Cin], coef_b [N,Cin], act): fused GroupNorm-apply(+FiLM)+activation on the conv input
@@ -195,9 +298,9 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
         oshape = (m, lin.n_p // 2 if act == ACT_GEGLU else lin.n_p)
     if lin.split:
         a.split_in = 1
-        if not out_f32:                                   # precise output: hi + lo pairs, 2*N 16-bit values per row
-            a.split_out = split_group(lin.n_p)
-            oshape = oshape[:-1] + (2 * lin.n_p,)
+    if (lin.split and not out_f32) or split_out:          # precise output: hi + lo pairs, 2*N 16-bit values per row (split_out: from plain f16
+        a.split_out = split_group(lin.n_p)                # operands too -- the mixed mode's attention projection back onto a split stream)
+        oshape = oshape[:-1] + (2 * lin.n_p,)
     if out is None:
         out = _empty(oshape, torch.float32 if out_f32 else _hip.TORCH_DTYPE[dt], a0.device)
     a.A0, a.A1, a.B = ptr(a0), ptr(a1), ptr(lin.w)
