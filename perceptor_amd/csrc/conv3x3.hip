@@ -432,16 +432,21 @@ extern "C" int pmi_conv3x3_halo_config(const pmi_igemm_args* a) {
   if (a->taps != 9 || a->stride != 1 || a->batch > 1) return -1;
   const int Cin = a->C0 + a->C1;
   // config 8: at most 32 input channels (the first convolution of the UNets): weights-direct tile with the whole K in registers
+  // (precise / mixed mode: the split input's 2 x 8 physical channels are this K too; the output is then split as well, Cout a multiple of 128)
   if (a->Bf && g_wd && g_wd_mf16 && g_wd_smallc && a->C1 == 0 && !a->A1 && a->C0 <= 32 && (a->C0 % 8) == 0 && !a->up && (a->W % 32) == 0 && (a->H % 8) == 0 && !a->pro_a &&
-      !a->split_out && !a->split_in && !a->out_f32 && !(a->R && a->res_f32) && (a->N % 32) == 0 && a->N >= 64 && (g_force_cfg < 0 || g_force_cfg == 8) &&
+      ((!a->split_out && !a->split_in) || (a->split_out == 32 && a->split_in == 1 && (a->N % 128) == 0 && a->dtype != PMI_DT_BF16)) &&
+      !a->out_f32 && !(a->R && a->res_f32) && (a->N % 32) == 0 && a->N >= 64 && (g_force_cfg < 0 || g_force_cfg == 8) &&
       (long)(a->M / (a->H * a->W)) * (a->H / 8) * (a->W / 32) * ((a->N + 127) / 128) >= (g_force_cfg == 8 ? 1 : 256))
     return 8;
   if ((Cin % 64) || (a->C0 % 64) || (a->W % 32) || (a->H % 8)) return -1;
-  if (a->split_out || a->split_in) {
+  // (a split input without a prologue whose output is NOT split -- the UNet's last convolution, fp32 out -- is a plain convolution over its
+  // 2C physical channels against duplicated weights: it takes the plain route below)
+  const bool plain_k = a->split_in == 1 && !a->split_out && !a->pro_a && a->out_f32 && a->N <= 32;
+  if ((a->split_out || a->split_in) && !plain_k) {
     // precise / mixed mode (hi + lo f16 pairs): the weights-direct kernel's 16x16x32 configs only.  Without a prologue a split input is an
     // ordinary K dimension of 2C physical channels against duplicated weights; with one the kernel stages (hi, lo) pairs (split_in 1: doubled
     // operand, 2: single operand over the logical channels).  The split epilogue writes [C/32][hi | lo] and takes the output statistics.
-    if (!a->Bf || !g_wd || !g_wd_mf16 || a->split_out != 32 || a->out_f32 || (a->R && a->res_f32) || (a->N % 128) || a->dtype == PMI_DT_BF16) return -1;
+    if (!a->Bf || !g_wd || !g_wd_mf16 || a->split_out != 32 || a->out_f32 || (a->N % 128) || a->dtype == PMI_DT_BF16) return -1;      // (an fp32 residual is fine: the same bytes as a split one)
     if (a->split_in == 2 && !a->pro_a) return -1;
     if (a->pro_a && (a->pro_act != PMI_ACT_SILU || !a->split_in)) return -1;
     const int cin_l = a->split_in == 1 ? Cin / 2 : Cin;     // the prologue's coefficient table counts logical channels

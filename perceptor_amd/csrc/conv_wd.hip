@@ -31,6 +31,9 @@
 #ifndef WLG
 #define WLG 1        // which group of a (dx, step) pair issues the next pair's weight loads: 0 = the first (two groups of latency cover), 1 = the second
 #endif
+#ifndef WD_ILV_SIN
+#define WD_ILV_SIN 4 // the same for the split-input staging (two loads, ~115 VALU instructions per unit): same-box A/B on the mixed c5 step: 2: 61.7 ms, 3: 60.9, 4: 60.7 (bf16 with 4: +0.7 ms, hence its own value)
+#endif
 #ifndef WD_ILV
 #define WD_ILV 2     // (4 until the last sweep: 2 leaves the 128-channel tiles 12 instead of 32 B/lane of scratch and measures +2 % there) VALU instructions of the patch staging the scheduler is asked to place behind each output row's MFMAs
 #endif
@@ -83,8 +86,12 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
   // groups, where only ONE weight set is live, so the prologue's temporaries fit the register file.
   constexpr int SG = (MF16 && 2 * (NPI - 1) <= NG - 2) ? 2 : 1;
   static_assert(SG * (NPI - 1) <= NG - 1, "the next patch must be complete before the barrier in the chunk's last group");
-  static_assert(2 * PATCH_BYTES + COEF_BYTES + PPIX_BYTES <= (NWN == 8 ? 160 : 80) * 1024 && EPI_BYTES <= (NWN == 8 ? 160 : 80) * 1024, "LDS budget");
-  __shared__ __attribute__((aligned(16))) char smem[cmax(2 * PATCH_BYTES + COEF_BYTES + PPIX_BYTES, EPI_BYTES)];
+  // bias + per-sample bias of the tile's BN channels: filled in the prologue (its global latency hides under the first patch loads), read by
+  // the epilogue -- which then starts without a load and without a barrier of its own; behind both the main loop's and the epilogue's regions
+  constexpr int BSM_OFF = cmax(2 * PATCH_BYTES + COEF_BYTES + PPIX_BYTES, EPI_BYTES - BN * 4);
+  static_assert(BSM_OFF + BN * 4 <= (NWN == 8 ? 160 : 80) * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) char smem[BSM_OFF + BN * 4];
+  float* const bsm = (float*)(smem + BSM_OFF);
   float* const coef = (float*)(smem + 2 * PATCH_BYTES);
   int* const ppix_s = (int*)(smem + 2 * PATCH_BYTES + COEF_BYTES);
 
@@ -218,8 +225,19 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc4[i][(r >> 3) & 1][(r >> 2) & 1][r & 3] = 0.f;
 
+  if (!SK) {
+    for (int c = tid; c < BN; c += NT) {                 // (made visible by the prologue's barrier)
+      const int n = n0 + c;
+      float b = 0.f;
+      if (n < a.N) {
+        if (a.bias) b = a.bias[n];
+        if (a.nbias) b += a.nbias[(int64_t)img * (a.ldnb ? a.ldnb : a.N) + n];
+      }
+      bsm[c] = b;
+    }
+  }
   if constexpr (SMALLC) {
-    static_assert(MF16 && NWN == 4 && PRO == 0 && !SPL && !SK, "config 8 is a 128-channel-tile instantiation");
+    static_assert(MF16 && NWN == 4 && PRO == 0 && !SK, "config 8 is a 128-channel-tile instantiation");
     const int Cp = a.C0, C8 = Cp >> 3;                     // 8 .. 32 input channels, one source
     const int KSS = (9 * Cp + 31) >> 5;                    // 32-deep MFMA steps over k = tap * Cp + c (3 .. 9); weights are zero past 9 * Cp
     const u16* const Ai = (const u16*)a.A0 + (int64_t)img * a.Hin * a.Win * a.lda0;
@@ -376,7 +394,7 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
         for (int i = i0; i < i1; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, MF16 ? 6 : 3, 0);   // the MFMAs of output row i
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);              // reload the freed fragment register
-          if (PRO && store_slot && i >= 2) __builtin_amdgcn_sched_group_barrier(0x002, WD_ILV * 4, 0);   // staging VALU, once the coefficients are in
+          if (PRO && store_slot && i >= 2) __builtin_amdgcn_sched_group_barrier(0x002, (SIN ? WD_ILV_SIN : WD_ILV) * 4, 0);   // staging VALU, once the coefficients are in
         }
       };
       if (g == NG - 1) {
@@ -439,14 +457,6 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
     constexpr int NWI = PXW / PPI;                       // iterations per wave and pass (8)
     char* const img_ = smem;
     float* const stat = (float*)(smem + NPX * FROW);     // [NW][HB][2] (sum, sumsq) partials per write-out wave, summed in a fixed order
-    float* const bsm = stat + NW * HB * 2;               // [BN] bias + per-sample bias
-    for (int c = tid; c < BN; c += NT) {
-      const int n = n0 + c;
-      float b = a.bias ? a.bias[n] : 0.f;
-      if (a.nbias) b += a.nbias[(int64_t)img * (a.ldnb ? a.ldnb : a.N) + n];
-      bsm[c] = b;
-    }
-    __syncthreads();                                     // bias visible; the main loop's last barrier already freed the patch buffers
     const int q = lane % LPR, psub = lane / LPR, cl0 = q * 8;
     typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
     constexpr int RD = 4;                                // residual prefetch depth (iterations): 8 registers each, the accumulators are still live
@@ -455,13 +465,15 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
       const int nq = n0 + hp * HB + cl0;                 // this lane's 8 logical output channels (inside one 32-group)
       const int po = split_off(nq, 32);                  // their high parts inside a pixel row; low parts 32 elements further
       uint4 rh[RD], rl[RD];
-      auto load_res = [&](int t) {
+      auto load_res = [&](int t) {                       // a split residual (16 B of high + 16 B of low parts) or an fp32 one (32 B): the same bytes
         const int p = wid * PXW + t * PPI + psub;
         const int y = y0 + (p >> 5), x = x0 + (p & 31);
         const int64_t rr = a.res_up ? (((int64_t)img * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.ldr
                                     : (((int64_t)img * a.H + y) * a.W + x) * a.ldr;
-        const u32x4_ h_ = __builtin_nontemporal_load((const u32x4_*)((const u16*)a.R + rr + po));
-        const u32x4_ l_ = __builtin_nontemporal_load((const u32x4_*)((const u16*)a.R + rr + po + 32));
+        const u32x4_* const r0 = a.res_f32 ? (const u32x4_*)((const float*)a.R + rr + nq) : (const u32x4_*)((const u16*)a.R + rr + po);
+        const u32x4_* const r1 = a.res_f32 ? r0 + 1 : (const u32x4_*)((const u16*)a.R + rr + po + 32);
+        const u32x4_ h_ = __builtin_nontemporal_load(r0);
+        const u32x4_ l_ = __builtin_nontemporal_load(r1);
         rh[t % RD] = make_uint4(h_.x, h_.y, h_.z, h_.w); rl[t % RD] = make_uint4(l_.x, l_.y, l_.z, l_.w);
       };
       if (a.R) {
@@ -489,6 +501,7 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
         });
       }
       __syncthreads();
+      if (hp == 0) STAMP(6);
       float cs[16];                                      // [0..7] sums, [8..15] sums of squares of this lane's 8 channels
 #pragma unroll
       for (int e = 0; e < 16; ++e) cs[e] = 0.f;
@@ -499,11 +512,17 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
         *(float4*)f = *(const float4*)(img_ + p * FROW + cl0 * 4);
         *(float4*)(f + 4) = *(const float4*)(img_ + p * FROW + cl0 * 4 + 16);
         if (a.R) {
-          float r0[8], r1[8];
-          unpack8<F16>(rh[t % RD], r0);
-          unpack8<F16>(rl[t % RD], r1);
+          if (a.res_f32) {
+            const uint4 u0 = rh[t % RD], u1 = rl[t % RD];
+            f[0] += __uint_as_float(u0.x); f[1] += __uint_as_float(u0.y); f[2] += __uint_as_float(u0.z); f[3] += __uint_as_float(u0.w);
+            f[4] += __uint_as_float(u1.x); f[5] += __uint_as_float(u1.y); f[6] += __uint_as_float(u1.z); f[7] += __uint_as_float(u1.w);
+          } else {
+            float r0[8], r1[8];
+            unpack8<F16>(rh[t % RD], r0);
+            unpack8<F16>(rl[t % RD], r1);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] += r0[e] + r1[e];
+            for (int e = 0; e < 8; ++e) f[e] += r0[e] + r1[e];
+          }
           if (t + RD < NWI) load_res(t + RD);
         }
 #pragma unroll
@@ -533,6 +552,7 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
         }
       }
       __syncthreads();                                   // every wave is done with the image (next pass overwrites it); statistic slots complete
+      if (hp == 0) STAMP(7);
       if (a.stats) {
         float* o = a.stats + (((int64_t)img * a.stats_p + ty * tiles_x + tx) * a.N + n0 + hp * HB) * 2;
         for (int c = tid; c < 2 * HB; c += NT) {
@@ -549,16 +569,6 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
   // ---- epilogue: the whole tile goes through LDS once and leaves as full pixel rows (BN x 2 B contiguous) ----
   char* const stg = smem;
   float* const stat = (float*)(smem + NPX * SROW);     // [NW][BN][2] (sum, sumsq) partials per write-out wave, summed in a fixed order
-  float* const bsm = stat + NW * BN * 2;               // [BN] bias + per-sample bias
-  for (int c = tid; c < BN; c += NT) {
-    const int n = n0 + c;
-    float b = 0.f;
-    if (n < a.N) {
-      if (a.bias) b = a.bias[n];
-      if (a.nbias) b += a.nbias[(int64_t)img * (a.ldnb ? a.ldnb : a.N) + n];
-    }
-    bsm[c] = b;
-  }
   constexpr int LPR = BN / 8;                          // lanes per output pixel row (16 bytes each): 32 / 16
   constexpr int PPI = 64 / LPR;                        // pixels per store instruction: 2 / 4
   constexpr int PXW = NPX / NW;                        // pixels written out by a wave: 32 / 64
@@ -582,7 +592,8 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
       rres[t] = make_uint4(r_.x, r_.y, r_.z, r_.w);
     }
   }
-  __syncthreads();                                     // bsm visible (the main loop's last barrier already freed the patch buffers)
+  // (no barrier here: the bias table is the prologue's, and the main loop's last barrier already freed the patch buffers -- what a slower
+  // wave still reads from them is a prefetch past the last chunk that nothing uses)
   // bias values of this lane's columns, read once (a read between the staging writes cannot be hoisted by the compiler: same LDS)
   act_switch(a.act, [&](auto act_c) __attribute__((always_inline)) {
     constexpr int ACT = decltype(act_c)::value;
@@ -685,10 +696,11 @@ int launch_p(const pmi_igemm_args& a, hipStream_t s, int cfg) {
   const int nimg = a.M / (a.H * a.W);
   if (a.split_out) {                                   // precise / mixed mode (hi + lo output): configs 6 / 7 only, f16 arithmetic
     const dim3 g7(nimg * (a.H / 8) * (a.W / 32) * (a.N / 128)), g6(nimg * (a.H / 8) * (a.W / 32) * (a.N / 256));
-    if (cfg != 6 && cfg != 7) return PMI_ERR_ARG;
+    if (cfg != 6 && cfg != 7 && !(cfg == 8 && PRO == 0)) return PMI_ERR_ARG;
     if constexpr (PRO == 0) {
       if (a.split_in == 2) return PMI_ERR_ARG;
-      if (cfg == 7) hipLaunchKernelGGL((conv3x3_wd_kernel<T, 0, true, 4, 32, true>), g7, dim3(256), 0, s, a);
+      if (cfg == 8) hipLaunchKernelGGL((conv3x3_wd_kernel<T, 0, true, 4, 32, true, false, true>), g7, dim3(256), 0, s, a);      // first convolution, split output
+      else if (cfg == 7) hipLaunchKernelGGL((conv3x3_wd_kernel<T, 0, true, 4, 32, true>), g7, dim3(256), 0, s, a);
       else hipLaunchKernelGGL((conv3x3_wd_kernel<T, 0, true, 8, 64, true>), g6, dim3(512), 0, s, a);
     } else if constexpr (PRO == 1 + PMI_ACT_SILU && std::is_same<T, F16>::value) {
       // fused GroupNorm-apply + SiLU over a split input: the doubled operand (split_in 1) or the single operand (split_in 2)
@@ -763,6 +775,12 @@ int pmi_conv3x3_wd_splitk(const pmi_igemm_args* a, int cfg) {
   return best;
 }
 
+// (Round 3: a start-time stagger of the first round's workgroups -- phase x chunks x ticks, so that the CUs' epilogue bursts spread over time --
+// was measured on the c5 step, mixed: 61.2 -> 62.4 / 63.9 / 65.6 ms at 3 / 6 / 10 us per chunk and phase, bf16: 42.3 -> 43.0 / 43.2: the
+// offsets only add idle time, the epilogues do not get faster when fewer CUs run them at once.  Removed.)
+// (Also measured and removed in round 3: split-output tiles starting their accumulators from the residual, loaded by each lane for its own
+// accumulator elements before the prologue, so that the epilogue's write-out is stores only.  The epilogue went 33.6 -> 20.9 us per tile but the
+// 8-byte accumulator-layout loads took 22 us of prologue: c5 mixed step 63.0 -> 64.6 ms on one box.)
 int pmi_conv3x3_wd_launch(const pmi_igemm_args* a, int cfg, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   return a->dtype == PMI_DT_BF16 ? launch_t<BF16>(*a, s, cfg) : launch_t<F16>(*a, s, cfg);

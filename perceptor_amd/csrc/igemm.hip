@@ -628,7 +628,7 @@ extern "C" int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream) {
   if (a->stride != 1 && a->stride != 2) return bad_arg(__LINE__);
   if (a->K != a->taps * (a->C0 + a->C1)) return bad_arg(__LINE__);
   if (a->R && (a->ldr & 3)) return bad_arg(__LINE__);
-  if (a->split_out && ((a->split_out != 8 && a->split_out != 32) || a->out_f32 || a->res_f32 || (a->N % a->split_out) || a->batch > 1)) return bad_arg(__LINE__);
+  if (a->split_out && ((a->split_out != 8 && a->split_out != 32) || a->out_f32 || (a->N % a->split_out) || a->batch > 1)) return bad_arg(__LINE__);
   if ((unsigned)a->split_in > 2u) return bad_arg(__LINE__);
   // (a fused prologue over split tensors and the single-operand form split_in = 2 exist in the weights-direct conv3x3 configs only: the
   // check behind the config query below rejects every other route)
@@ -641,7 +641,7 @@ extern "C" int pmi_igemm(const pmi_igemm_args* a, pmi_stream_t stream) {
   if (a->batch > 1 && a->batch_inner <= 0) return bad_arg(__LINE__);
   const int halo = g_allow_halo ? pmi_conv3x3_halo_config(a) : -1;
   if (a->pro_a && (!a->pro_b || halo < 0)) return PMI_ERR_ARG;
-  if ((a->split_in == 2 || ((a->split_in || a->split_out) && a->pro_a)) && halo < 6) return bad_arg(__LINE__);
+  if ((a->split_in == 2 || ((a->split_in || a->split_out) && a->pro_a) || (a->split_out && a->R && a->res_f32)) && halo < 6) return bad_arg(__LINE__);
   if (a->stats && a->stats_p != pmi_igemm_stats_rows(a)) return PMI_ERR_ARG;
   if (a->splitk > 1 && (!a->ws || a->batch > 1 || (halo >= 0 && a->splitk != pmi_conv3x3_wd_splitk(a, halo)) || (a->N & 3) || a->stats)) return PMI_ERR_ARG;
   if (a->act == PMI_ACT_GEGLU && !pmi_gemm_wd_eligible(a)) return bad_arg(__LINE__);     // the gated epilogue exists in the weights-direct GEMM only

@@ -13,8 +13,9 @@ the 3x3 convolution operands 19 %, conv1 outputs 9 %, the network input 5 %, the
   * 3x3 convolution OPERANDS, act(GroupNorm(x)) staged by the kernel's fused prologue, are a single f16 value where the sweep shows the layer's
     share is small (62 % of the conv FLOPs: every layer from 1/8 resolution down, the 256-channel up-sampling blocks, half of the 1/2 and 1/4
     levels) and a hi + lo pair (doubled K) elsewhere -- the 128-channel full-resolution layers and the output convolution.  The choice is a
-    per-layer table (`MIXED_SINGLE_STANDARD`, chosen greedily by error variance per FLOP under an rms budget of 1e-4; predicted max-abs
-    4.8e-4) for the shipped 512x512 config and a by-level rule for any other.
+    per-layer table (`MIXED_SINGLE_STANDARD`, chosen greedily by error variance per FLOP under an rms budget of 1e-4, then two more layers by
+    measured time per variance: predicted rms 1.2e-4, max-abs 5.7-6.6e-4 over sizes / timesteps) for the shipped 512x512 config and a by-level
+    rule for any other.
   * Attention blocks run their internals in plain f16 from a split input and add onto the split stream.
   * The two deepest levels (1/32, 1/64: 16x16 and 8x8 maps at 512x512) run the plain f16 engine (adm.AdmEngine's blocks): +8 % rms.
 
@@ -39,7 +40,10 @@ MIXED_SINGLE_STANDARD = frozenset(
     + [f"middle_block.{i}.{c}" for i in (0, 2) for c in ("conv1", "conv2")]
     + [f"output_blocks.{i}.0.{c}" for i in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15) for c in ("conv1", "conv2")]
     + [f"output_blocks.{i}.{c}" for i in ("2.2", "5.2", "8.2", "11.1", "14.1", "17.1") for c in ("conv1", "conv2")]
-    + ["output_blocks.16.0.conv1", "output_blocks.18.0.conv1"])
+    + ["output_blocks.16.0.conv1", "output_blocks.18.0.conv1"]
+    # two more by measured TIME per variance (the greedy above counts FLOPs; a doubled 128-channel layer at full resolution costs 1.4 ms against
+    # 0.76 single, the 768 -> 256 one at half resolution 1.5 against 0.86): rms 1.07e-4 -> 1.17e-4 predicted, -1.3 ms per c5 step
+    + ["output_blocks.17.0.conv1", "output_blocks.18.0.conv2"])
 
 
 def annotate_levels(cfg: AdmConfig, inp, mid, out) -> None:
@@ -149,7 +153,8 @@ class AdmMixedEngine(AdmEngine):
         else:
             ca, cb = ops.group_norm_coeffs(h, g2, b2, 32, dt)
         if l.cin != l.cout:
-            skip = ops.igemm(skip, w[l.p + ".skip"], a1=skip1)        # hi + lo operands: the sweep's second largest share
+            # hi + lo operands (the sweep's second largest share) on the weights-direct GEMM; its fp32 rows are the residual of conv2's epilogue
+            skip = ops.igemm(skip, w[l.p + ".skip"], a1=skip1, out_f32=True)
         elif skip1 is not None:
             raise NotImplementedError("identity skip over a concatenated input does not occur in the shipped configs")
         return ops.conv3x3_mixed(h, w[l.p + ".conv2"], residual=skip, res_up=l.up, prologue=(ca, cb, ACT_SILU),

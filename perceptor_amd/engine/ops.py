@@ -236,13 +236,17 @@ def conv3x3_mixed(x: torch.Tensor, mlin: MixedLinear, *, operand: str, prologue,
     a.split_in, a.split_out = (2 if operand == "single" else 1), 32
     a.A0, a.A1, a.B, a.bias, a.nbias, a.R = ptr(x), ptr(x1), ptr(lin.w), ptr(lin.b), ptr(nbias), ptr(residual)
     a.ldb, a.ldr, a.ldnb = lin.K, (residual.stride(-2) if residual is not None else 0), (nbias.stride(0) if nbias is not None else 0)
+    a.res_f32 = int(residual is not None and residual.dtype == torch.float32)     # an fp32 residual (the 1x1 skip_connection's output) costs the same bytes as a split one
     a.pro_a, a.pro_b, a.pro_act, a.Bf = 1, 1, pact, 1      # markers for the config query
     cfg = _hip.lib().pmi_conv3x3_halo_config(C.byref(a)) if (lin.n_p % 128 == 0 and lin.K == 9 * (c0 + c1) and WD_ENABLED and HALO_ENABLED) else -1
     if MIXED_TRACE is not None:
         MIXED_TRACE.append(("wd" if cfg >= 6 else "fallback", operand, (n, h, w, c0 + c1, lin.cout)))
     if cfg < 6:
-        d = mlin.dbl
-        return igemm(x, d, a1=x1, up=up, residual=residual, res_up=res_up, nbias=nbias, prologue=prologue, want_stats=True)
+        if residual is not None and residual.dtype == torch.float32:      # the generic split epilogue reads a split residual
+            rs = _empty(residual.shape[:-1] + (2 * residual.shape[-1],), torch.float16, x.device)
+            call("pmi_split_from_f32", ptr(residual), residual.stride(-2), ptr(rs), residual.numel() // residual.shape[-1], residual.shape[-1])
+            residual = rs
+        return igemm(x, mlin.dbl, a1=x1, up=up, residual=residual, res_up=res_up, nbias=nbias, prologue=prologue, want_stats=True)
     ck = 64 if cfg == 6 else 32
     a.Bf = ptr(lin.frag16(ck) if operand == "single" else lin.frag16(ck, dup_g=ck // 2))
     a.pro_a, a.pro_b, a.pro_act = ptr(ca), ptr(cb), pact
@@ -253,6 +257,9 @@ def conv3x3_mixed(x: torch.Tensor, mlin: MixedLinear, *, operand: str, prologue,
         st = _empty((n, rows, lin.n_p, 2), torch.float32, x.device)
         a.stats, a.stats_p = ptr(st), rows
         out._pmi_stats = (st, rows)
+    if DEBUG_WS is not None:
+        a.ws = ptr(DEBUG_WS)
+        a.reserved = 77
     if KERNEL_EVENTS is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -317,7 +324,7 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
     a.ldnb = nbias.stride(0) if nbias is not None else 0
     a.batch, a.batch_inner = 1, 1
     a.dtype = dt
-    if conv and lin.taps == 9 and stride == 1 and HALO_ENABLED and WD_ENABLED and lin.n_p % 32 == 0 and ((lin.n_p >= 128 and lin.cin_p % 64 == 0) or (lin.cin_p <= 32 and a1 is None and not lin.split)):
+    if conv and lin.taps == 9 and stride == 1 and HALO_ENABLED and WD_ENABLED and lin.n_p % 32 == 0 and ((lin.n_p >= 128 and lin.cin_p % 64 == 0) or (lin.cin_p <= 32 and a1 is None)):
         a.Bf = 1                       # ask which tile config the weights-direct kernel would run, then hand it that packing
         a.pro_a = 1 if (prologue is not None and not lin.split) else None     # (the table size limit depends on a fused prologue)
         cfg = _hip.lib().pmi_conv3x3_halo_config(C.byref(a))
@@ -325,7 +332,8 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
         a.Bf = ptr(lin.frag16(64)) if cfg == 6 else ptr(lin.frag16(32)) if cfg == 7 else ptr(lin.frag(64)) if cfg == 4 else ptr(lin.frag_c8()) if cfg == 8 else None
     if pre_out is not None or act_grad_of is not None:
         a.D2, a.aux, a.aux_act = ptr(pre_out), ptr(act_grad_of), act_grad
-    wd_ok = GEMM_WD_ENABLED and lin.taps == 1 and not lin.split and not up and stride == 1 and lin.n_p % 32 == 0 and lin.K % 32 == 0 \
+    # (split weights: their duplicated K is an ordinary K for the weights-direct GEMM; its epilogues write plain 16-bit or fp32 rows only)
+    wd_ok = GEMM_WD_ENABLED and lin.taps == 1 and (not lin.split or out_f32) and not up and stride == 1 and lin.n_p % 32 == 0 and lin.K % 32 == 0 \
         and nbias is None and prologue is None
     if wd_ok and want_stats:
         # the weights-direct GEMM has no statistics epilogue; the generic kernel has none either once it splits K (attention proj_out on

@@ -49,6 +49,9 @@ CASES = [
     dict(n=1, h=16, w=32, cin=384, cout=128, cfg=7, split=256, res=True),
     dict(n=1, h=8, w=16, cin=64, cout=128, cfg=7, up=True, res_up=True),
     dict(n=1, h=16, w=16, cin=64, cout=128, cfg=-1, res=True),                 # W % 32 != 0: the generic fallback (always the doubled operand)
+    dict(n=1, h=16, w=32, cin=128, cout=256, cfg=6, res=True, res_f32=True),   # fp32 residual: the 1x1 skip_connection's rows (weights-direct GEMM)
+    dict(n=1, h=16, w=32, cin=384, cout=128, cfg=7, split=256, res=True, res_f32=True),
+    dict(n=1, h=16, w=16, cin=64, cout=128, cfg=-1, res=True, res_f32=True),
 ]
 
 
@@ -85,8 +88,9 @@ def test_conv3x3_mixed_vs_torch(case, operand):
     res = None
     if case.get("res") or case.get("res_up"):
         rshape = (n, ho // 2, wo // 2, cout) if case.get("res_up") else (n, ho, wo, cout)
-        res = to_split(torch.randn(*rshape, generator=g))
-        rv = from_split(res)
+        rv = torch.randn(*rshape, generator=g)
+        res = rv.clone() if case.get("res_f32") else to_split(rv)
+        rv = rv if case.get("res_f32") else from_split(res)
         if case.get("res_up"):
             rv = F.interpolate(rv.permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1)
         ref = ref + rv

@@ -11,6 +11,7 @@ p.add_argument("--n", type=int, default=8); p.add_argument("--hw", type=int, def
 p.add_argument("--cin", type=int, default=256); p.add_argument("--cout", type=int, default=256)
 p.add_argument("--iters", type=int, default=20); p.add_argument("--dtype", default="bf16")
 p.add_argument("--halo", type=int, default=1); p.add_argument("--pro", type=int, default=0)
+p.add_argument("--mixed", default="", help="single | dbl: the mixed-mode convolution (split input / output, fused prologue) through ops.conv3x3_mixed")
 p.add_argument("--rounds", type=int, default=3); p.add_argument("--cfg", type=int, default=-1); p.add_argument("--dbg", type=int, default=0); p.add_argument("--stamps", type=int, default=0); p.add_argument("--res", type=int, default=0); p.add_argument("--stats", type=int, default=0)
 a = p.parse_args()
 dev = torch.device("cuda:0")
@@ -27,7 +28,23 @@ flops = 2.0 * a.n * a.hw * a.hw * a.cin * a.cout * 9
 from perceptor_amd import _hip
 _hip.lib().pmi_set_option(1, a.cfg)
 STAMP = None
-for halo in ([a.halo] if a.halo in (0, 1) else [0, 1]):
+if a.mixed:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    xs = ops.split_convert(x.to(torch.float16), True)
+    ml = ops.MixedLinear(w, torch.zeros(a.cout), dev)
+    pro = (torch.ones(a.n, a.cin, device=dev), torch.zeros(a.n, a.cin, device=dev), 2)
+    res = ops.split_convert(torch.randn(a.n, a.hw, a.hw, a.cout, generator=g).to(torch.float16).to(dev), True) if a.res else None
+    run = lambda: ops.conv3x3_mixed(xs, ml, operand=a.mixed, prologue=pro, residual=res)
+    run(); torch.cuda.synchronize()
+    for r in range(a.rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            run()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        print(f"mixed-{a.mixed} cfg={a.cfg} n={a.n} hw={a.hw} cin={a.cin} cout={a.cout} res={a.res}: {ms:.3f} ms  {flops / ms / 1e9:.1f} TFLOP/s (algorithmic)", flush=True)
+for halo in ([] if a.mixed else [a.halo] if a.halo in (0, 1) else [0, 1]):
     ops.set_halo(bool(halo))
     res = torch.randn(a.n, a.hw, a.hw, a.cout, generator=g).to(td).to(dev) if a.res else None
     out = ops.igemm(x, lin, prologue=pro, residual=res, want_stats=bool(a.stats))
@@ -47,7 +64,10 @@ if a.stamps:
     ops.set_halo(True)
     ws = torch.zeros(1 << 20, dtype=torch.int64, device=dev)   # [0, 2^19): phase stamps, 8 per workgroup; [2^19, ...): 4 per wave
     ops.DEBUG_WS = ws
-    ops.igemm(x, lin, prologue=pro, out=out, residual=res, want_stats=bool(a.stats))
+    if a.mixed:
+        run()
+    else:
+        ops.igemm(x, lin, prologue=pro, out=out, residual=res, want_stats=bool(a.stats))
     torch.cuda.synchronize()
     ops.DEBUG_WS = None
     st = ws.cpu()[:1 << 19].view(-1, 8)
