@@ -464,15 +464,22 @@ def main():
                         evs = [kernel_events[st * per + k] for st in range(a.steps)]
                         ms = sum(e[0].elapsed_time(e[1]) for e in evs) / a.steps
                         f.write(f"{k:3d} {ms:8.4f} ms {evs[0][2] / 1e9:10.1f} GFLOP {evs[0][3] / 1e6:9.1f} MB {evs[0][2] / 1e9 / ms:8.1f} TFLOP/s {evs[0][3] / 1e6 / ms:8.1f} GB/s {evs[0][4]}\n")
-            pmc = os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")
-            if a.config == "c5" and a.dtype == "bf16" and os.path.exists(pmc):    # HBM bytes per conv3x3 launch from the committed PMC passes
+            # HBM bytes per conv3x3 launch from the committed PMC passes of this command -- only while the profile belongs to these kernels
+            # (sha of the conv sources recorded by tools/pmc_summary.py); a stale profile leaves `traffic` null and says so
+            pmc = os.path.join(ROOT, "profiles", "r03_pmc_hbm.json" if a.dtype == "bf16" else f"r03_pmc_hbm_{a.dtype}.json")
+            if a.config == "c5" and os.path.exists(pmc):
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from pmc_summary import kernel_src_sha16
                 with open(pmc) as f:
                     rows = json.load(f)
-                rows = [rows[k] for k in ("conv3x3_wd_kernel", "conv3x3_halo_kernel") if k in rows]
-                if rows:
-                    roof["traffic"] = round(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in rows) / sum(r["launches"] for r in rows))
-                    roof["traffic_note"] = ("profiles/r02_pmc_hbm.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch, launch-weighted over "
-                                            "conv3x3_wd_kernel and conv3x3_halo_kernel; separate rocprofv3 --pmc passes of this command")
+                if rows.get("_kernel_src_sha16") == kernel_src_sha16():
+                    krows = [rows[k] for k in ("conv3x3_wd_kernel", "conv3x3_halo_kernel") if k in rows]
+                    if krows:
+                        roof["traffic"] = round(sum(r["hbm_bytes_per_launch"] * r["launches"] for r in krows) / sum(r["launches"] for r in krows))
+                        roof["traffic_source"] = (f"profiles/{os.path.basename(pmc)} (kernel sources unchanged since its collection): (2*FETCH_SIZE + WRITE_SIZE) KiB per "
+                                                  "launch, launch-weighted over conv3x3_wd_kernel and conv3x3_halo_kernel; separate rocprofv3 --pmc passes of this command")
+                else:
+                    roof["traffic_stale_profile"] = f"profiles/{os.path.basename(pmc)} was collected on other conv kernel sources: traffic left null"
         else:
             roof.update({"achieved": step_roof["achieved"], "frac": step_roof["frac"], "kernel": "whole step (no per-kernel events)"})
         out = {

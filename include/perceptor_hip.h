@@ -248,6 +248,17 @@ int pmi_add16(const void* a, const void* b, void* out, int64_t n, int dtype, pmi
 int pmi_avgpool2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, pmi_stream_t s);
 int pmi_upsample_bilinear2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, pmi_stream_t s);
 int pmi_upsample_nearest2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, pmi_stream_t s);   /* wikiart_256.py:117 */
+/* GroupNorm32 (+FiLM) + activation backward of the ADM UNet (unet.py:232-252 out_layers / in_layers, nn.py:17-19; the gradient autograd forms
+ * when GuidedDiffusion.predicted_noise is differentiated, guided_diffusion.py:125-133).  The forward is y = act(a x + b) with pmi_gn_finalize's
+ * coefficients; stats: per-channel partials of dt = dy act'(a x + b) and dt x, ws [N][nchunk][C][2]; finalize: from the FORWARD partials s0 / s1
+ * (as given to pmi_gn_finalize) and those, P / Q per channel; apply: dx = a dt + P x + Q (+ gadd), one output per concat source. */
+int pmi_gn_bwd_stats(const void* x, const void* x1, int C0, const void* dy, const float* coef_a, const float* coef_b, int act, float* ws,
+                     int N, int HW, int C, int nchunk, int dtype, pmi_stream_t s);
+int pmi_gn_bwd_finalize(const float* s0, int P0, int C0, const float* s1, int P1, int C1, const float* ws_bwd, int PB, const float* gamma,
+                        const float* film, int film_ld, float* coef_p, float* coef_q, int N, int HW, int G, float eps, pmi_stream_t s);
+int pmi_gn_bwd_apply(const void* x, const void* x1, int C0, const void* dy, const float* coef_a, const float* coef_b, const float* coef_p,
+                     const float* coef_q, int act, const void* gadd0, const void* gadd1, void* dx0, void* dx1, int N, int HW, int C,
+                     int dtype, pmi_stream_t s);
 int pmi_gn1_bwd_partials(int64_t hw, int C);   /* slices per sample: the caller passes partial = N * this * 4 doubles of workspace */
 int pmi_gn1_bwd(const void* x, const void* dy, const float* gamma, int gamma_ld, float gamma_add, const void* res, void* dx,
                 double* partial, int N, int64_t hw, int C, float eps, int dtype, pmi_stream_t s);

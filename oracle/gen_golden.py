@@ -161,6 +161,39 @@ def gen_adm():
         save(f"adm_{name}_{res}", x=x, t=t, y_sub=y[:, :, ::4, ::4].contiguous(), y_mom=moments(y))
 
 
+def gen_adm_grad():
+    """Row f2, ADM UNet: the input gradient autograd computes through the reference's UNetModel -- upstream GuidedDiffusion.predicted_noise is
+    differentiable (guided_diffusion.py:125-133) and its blocks run through CheckpointFunction (nn.py:138-189, unet.py:228-229, 292), whose
+    recomputation gives autograd's gradient.  d sum(probe * eps) / d x with eps = the first 3 output channels (what predicted_noise returns):
+    both tiny configs (both attention orders, both ResBlock flavours, up / down blocks) and the shipped 558 M-parameter net at 128x128."""
+    su = R.ref("models.guided_diffusion.script_util")
+    cm = R.ref("models.guided_diffusion.create_models")
+    for tag, kw in ADM_TINY.items():
+        m = su.create_model(**kw).eval()
+        m.load_state_dict(synth_like(m.state_dict(), 0))
+        for p_ in m.parameters():
+            p_.requires_grad_(False)
+        x = seeded_noise((2, 3, 64, 64), 31).requires_grad_(True)
+        t = torch.tensor([10, 500])
+        probe = seeded_noise((2, 3, 64, 64), 61)
+        y = m(x, t)
+        (g,) = torch.autograd.grad((y[:, :3] * probe).sum(), x)
+        save(f"adm_tiny_{tag}_grad", t=t, g=g, y_mom=moments(y.detach()))
+    m, _ = cm.create_openimages_model()
+    m.convert_to_fp32()
+    m.dtype = torch.float32
+    m.eval()
+    m.load_state_dict(synth_like(m.state_dict(), 0))
+    for p_ in m.parameters():
+        p_.requires_grad_(False)
+    x = seeded_noise((1, 3, 128, 128), 32).requires_grad_(True)
+    t = torch.tensor([333])
+    probe = seeded_noise((1, 3, 128, 128), 62)
+    y = m(x, t)
+    (g,) = torch.autograd.grad((y[:, :3] * probe).sum(), x)
+    save("adm_standard_128_grad", t=t, g_sub=g[:, :, ::2, ::2].contiguous(), g_mom=moments(g), y_mom=moments(y.detach()))
+
+
 def gen_adm_fp16w():
     """Weights as a real checkpoint has them: full-precision fp32 values, of which the reference's own convert_to_fp16()
     (unet.py:610-616, fp16_util.py:16-23) casts the torso convolutions to fp16 -- NOT bf16-representable, so packing them to bf16

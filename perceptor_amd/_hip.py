@@ -110,6 +110,9 @@ _PROTOS = {
     "pmi_avgpool2_bwd": ([_P, _P, _I, _I, _I, _I, _I, _P],),
     "pmi_upsample_bilinear2_bwd": ([_P, _P, _I, _I, _I, _I, _I, _P],),
     "pmi_upsample_nearest2_bwd": ([_P, _P, _I, _I, _I, _I, _I, _P],),
+    "pmi_gn_bwd_stats": ([_P, _P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],),
+    "pmi_gn_bwd_finalize": ([_P, _I, _I, _P, _I, _I, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _F, _P],),
+    "pmi_gn_bwd_apply": ([_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],),
     "pmi_gn1_bwd_partials": ([_L, _I],),
     "pmi_gn1_bwd": ([_P, _P, _P, _I, _F, _P, _P, _P, _I, _L, _I, _F, _I, _P],),
     # CLIP path (clip.hip)

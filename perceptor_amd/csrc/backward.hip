@@ -8,6 +8,11 @@
 //   pmi_upsample_nearest2_bwd   adjoint of nn.Upsample(2, 'nearest')                          (wikiart_256.py:117)
 //   pmi_gn1_bwd                 backward of GroupNorm(1, C) with a shared affine weight (SelfAttention2d.norm, yfcc_2.py:41-52) or a per-sample
 //                               FiLM scale (Modulation2d after GroupNorm(1, C, affine=False), cc12m_1.py:33-61), plus an optional residual path
+//   pmi_gn_bwd_stats / _finalize / _apply   (round 3) backward of GroupNorm32 (+ FiLM) + activation of the ADM UNet (unet.py:232-252, nn.py:17-19),
+//                               G groups, one or two (skip-concat) sources: the forward is y = act(a[n][c] x + b[n][c]) with the coefficients of
+//                               pmi_gn_finalize, so with dt = dy act'(a x + b):  dx = a dt + P[n][g] x + Q[n][g],
+//                               P = -r^2 m2, Q = -r m1 + r^2 mu m2, m1 = mean_g(gamma' dt), m2 = mean_g(gamma' dt xhat) -- three streaming passes
+//                               shaped like the forward's stats / finalize / apply
 #include "../../include/perceptor_hip.h"
 #include "common.h"
 
@@ -202,6 +207,133 @@ inline unsigned grid_for(int64_t items) {
   return (unsigned)(b < 1 ? 1 : (b > 65535 * 16 ? 65535 * 16 : b));
 }
 
+
+// ---- GroupNorm(G) (+FiLM) + activation backward (ADM UNet) --------------------------------------------------------------------------
+// stats: per (sample, pixel chunk, channel) partials A = sum_p dt, B = sum_p dt * x with dt = dy * act'(a x + b); x = concat of two sources.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const u16* __restrict__ x, const u16* __restrict__ x1, int C0, const u16* __restrict__ dy,
+                                                           const float* __restrict__ ca, const float* __restrict__ cb, int act,
+                                                           float* __restrict__ ws, int HW, int C, int nchunk) {
+  __shared__ float s_a[4096], s_b[4096];          // [PPI][C] slots, one per pixel lane (PPI * C <= 4096): no float atomics, fixed order
+  const int tid = threadIdx.x, chunk = blockIdx.x, n = blockIdx.y;
+  const int C8 = C >> 3;
+  const int TPP = C8 < 256 ? C8 : 256;
+  const int PPI = 256 / TPP;
+  const int my_p = tid / TPP, my_c = tid - my_p * TPP;
+  const int ppc = (HW + nchunk - 1) / nchunk;
+  const int p0 = chunk * ppc, p1 = min(HW, p0 + ppc);
+  const int C1 = C - C0;
+  if (my_p < PPI) {
+    for (int c8 = my_c; c8 < C8; c8 += TPP) {
+      const bool second = c8 * 8 >= C0;
+      const int Cs = second ? C1 : C0, cl = second ? c8 * 8 - C0 : c8 * 8;
+      const u16* xb = (second ? x1 : x) + (int64_t)n * HW * Cs;
+      const u16* db = dy + (int64_t)n * HW * C;
+      float a[8], b[8], sa[8], sb[8];
+      *(float4*)a = *(const float4*)(ca + (int64_t)n * C + c8 * 8); *(float4*)(a + 4) = *(const float4*)(ca + (int64_t)n * C + c8 * 8 + 4);
+      *(float4*)b = *(const float4*)(cb + (int64_t)n * C + c8 * 8); *(float4*)(b + 4) = *(const float4*)(cb + (int64_t)n * C + c8 * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sa[e] = 0.f; sb[e] = 0.f; }
+      for (int p = p0 + my_p; p < p1; p += PPI) {
+        float f[8], d[8];
+        unpack8<T>(*(const uint4*)(xb + (int64_t)p * Cs + cl), f);
+        unpack8<T>(*(const uint4*)(db + (int64_t)p * C + c8 * 8), d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dt = d[e] * act_grad(a[e] * f[e] + b[e], act);
+          sa[e] += dt; sb[e] += dt * f[e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s_a[my_p * C + c8 * 8 + e] = sa[e]; s_b[my_p * C + c8 * 8 + e] = sb[e]; }
+    }
+  }
+  __syncthreads();
+  float* o = ws + ((int64_t)n * nchunk + chunk) * C * 2;
+  for (int c = tid; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int pl = 0; pl < PPI; ++pl) { a += s_a[pl * C + c]; b += s_b[pl * C + c]; }
+    o[2 * c] = a; o[2 * c + 1] = b;
+  }
+}
+
+// finalize: one workgroup per (sample, group).  Forward moments (mu, r) from the forward's per-channel (sum, sumsq) partials -- the same
+// double-precision combination as gn_finalize_kernel -- then m1, m2 from the backward partials; writes P, Q per channel of the group.
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ s0, int P0, int C0, const float* __restrict__ s1, int P1, int C1,
+                                                              const float* __restrict__ wsb, int PB, const float* __restrict__ gamma,
+                                                              const float* __restrict__ film, int film_ld, float* __restrict__ cp,
+                                                              float* __restrict__ cq, int HW, int G, float eps) {
+  __shared__ double red[4][4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, n = blockIdx.x, g = blockIdx.y;
+  const int C = C0 + C1, cpg = C / G, g_lo = g * cpg;
+  double s = 0.0, q = 0.0, a1 = 0.0, a2 = 0.0;          // forward sum, sumsq; backward sum gamma' A, sum gamma' B
+  for (int j = 0; j < cpg; ++j) {
+    const int c = g_lo + j;
+    const bool second = c >= C0;
+    const float* base = second ? s1 + (int64_t)n * P1 * C1 * 2 : s0 + (int64_t)n * P0 * C0 * 2;
+    const int P = second ? P1 : P0, Cs = second ? C1 : C0, cl = second ? c - C0 : c;
+    float gm = gamma ? gamma[c] : 1.f;
+    if (film) gm *= 1.f + film[(int64_t)n * film_ld + c];
+    double fs = 0.0, fq = 0.0, ba = 0.0, bb = 0.0;
+    for (int pr = tid; pr < P; pr += 256) { const float2 v = *(const float2*)(base + ((int64_t)pr * Cs + cl) * 2); fs += v.x; fq += v.y; }
+    for (int pr = tid; pr < PB; pr += 256) { const float2 v = *(const float2*)(wsb + (((int64_t)n * PB + pr) * C + c) * 2); ba += v.x; bb += v.y; }
+    s += fs; q += fq; a1 += (double)gm * ba; a2 += (double)gm * bb;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }
+  if (lane == 0) { red[0][wid] = s; red[1][wid] = q; red[2][wid] = a1; red[3][wid] = a2; }
+  __syncthreads();
+  s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  a1 = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+  a2 = red[3][0] + red[3][1] + red[3][2] + red[3][3];
+  const double cnt = (double)HW * cpg;
+  const double mu = s / cnt;
+  double var = q / cnt - mu * mu;
+  if (var < 0.0) var = 0.0;
+  const double r = 1.0 / sqrt(var + (double)eps);
+  const double m1 = a1 / cnt;                            // mean_g(gamma' dt)
+  const double m2 = r * (a2 - mu * a1) / cnt;            // mean_g(gamma' dt xhat), xhat = (x - mu) r
+  const float Pv = (float)(-r * r * m2), Qv = (float)(-r * m1 + r * r * mu * m2);
+  for (int j = tid; j < cpg; j += 256) { cp[(int64_t)n * C + g_lo + j] = Pv; cq[(int64_t)n * C + g_lo + j] = Qv; }
+}
+
+// apply: dx = a dt + P x + Q (+ gadd: the gradient arriving over the block's skip path), written per source
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const u16* __restrict__ x, const u16* __restrict__ x1, int C0, const u16* __restrict__ dy,
+                                                           const float* __restrict__ ca, const float* __restrict__ cb, const float* __restrict__ cp,
+                                                           const float* __restrict__ cq, int act, const u16* __restrict__ gadd0,
+                                                           const u16* __restrict__ gadd1, u16* __restrict__ dx0, u16* __restrict__ dx1,
+                                                           int N, int HW, int C) {
+  const int C8 = C >> 3, C1 = C - C0;
+  const int64_t total = (int64_t)N * HW * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t pix = i / C8;
+    const int n = (int)(pix / HW);
+    const bool second = c8 * 8 >= C0;
+    const int Cs = second ? C1 : C0, cl = second ? c8 * 8 - C0 : c8 * 8;
+    const int64_t off = pix * Cs + cl;
+    float f[8], d[8], a[8], b[8], pp[8], qq[8], o[8];
+    unpack8<T>(*(const uint4*)((second ? x1 : x) + off), f);
+    unpack8<T>(*(const uint4*)(dy + pix * C + c8 * 8), d);
+    const int64_t co = (int64_t)n * C + c8 * 8;
+    *(float4*)a = *(const float4*)(ca + co); *(float4*)(a + 4) = *(const float4*)(ca + co + 4);
+    *(float4*)b = *(const float4*)(cb + co); *(float4*)(b + 4) = *(const float4*)(cb + co + 4);
+    *(float4*)pp = *(const float4*)(cp + co); *(float4*)(pp + 4) = *(const float4*)(cp + co + 4);
+    *(float4*)qq = *(const float4*)(cq + co); *(float4*)(qq + 4) = *(const float4*)(cq + co + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = a[e] * (d[e] * act_grad(a[e] * f[e] + b[e], act)) + pp[e] * f[e] + qq[e];
+    const u16* ga = second ? gadd1 : gadd0;
+    if (ga) {
+      float r[8];
+      unpack8<T>(*(const uint4*)(ga + off), r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += r[e];
+    }
+    *(uint4*)((second ? dx1 : dx0) + off) = pack8<T>(o);
+  }
+}
 }  // namespace
 
 #define ST ((hipStream_t)s)
@@ -259,6 +391,45 @@ extern "C" int pmi_gn1_bwd(const void* x, const void* dy, const float* gamma, in
   PMI_CHECK_LAUNCH();
   BY16(gn1_bwd_apply_kernel, dim3(P, N), dim3(GT), (const u16*)x, (const u16*)dy, gamma, gamma_ld, gamma_add, (const u16*)res, (u16*)dx,
        partial, hw, C, P, eps);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+
+extern "C" int pmi_gn_bwd_stats(const void* x, const void* x1, int C0, const void* dy, const float* coef_a, const float* coef_b, int act, float* ws,
+                                int N, int HW, int C, int nchunk, int dtype, pmi_stream_t s) {
+  if (!x || !dy || !coef_a || !coef_b || !ws || N <= 0 || HW <= 0 || C <= 0 || (C & 7) || (C0 & 7) || C0 > C || (C0 < C && !x1) || nchunk <= 0 ||
+      dtype == PMI_DT_F16X2)
+    return PMI_ERR_ARG;
+  const int C8 = C >> 3, TPP = C8 < 256 ? C8 : 256, PPI = 256 / TPP;
+  if (PPI * C > 4096) return PMI_ERR_ARG;
+  dim3 grid(nchunk, N), block(256);
+  hipStream_t st = (hipStream_t)s;
+  if (dtype == PMI_DT_BF16) hipLaunchKernelGGL(gn_bwd_stats_kernel<BF16>, grid, block, 0, st, (const u16*)x, (const u16*)x1, C0, (const u16*)dy, coef_a, coef_b, act, ws, HW, C, nchunk);
+  else hipLaunchKernelGGL(gn_bwd_stats_kernel<F16>, grid, block, 0, st, (const u16*)x, (const u16*)x1, C0, (const u16*)dy, coef_a, coef_b, act, ws, HW, C, nchunk);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_gn_bwd_finalize(const float* s0, int P0, int C0, const float* s1, int P1, int C1, const float* ws_bwd, int PB, const float* gamma,
+                                   const float* film, int film_ld, float* coef_p, float* coef_q, int N, int HW, int G, float eps, pmi_stream_t s) {
+  const int C = C0 + C1;
+  if (!s0 || !ws_bwd || !coef_p || !coef_q || N <= 0 || HW <= 0 || G <= 0 || C <= 0 || (C % G) || P0 <= 0 || PB <= 0 || (C1 > 0 && (!s1 || P1 <= 0)))
+    return PMI_ERR_ARG;
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(N, G), dim3(256), 0, (hipStream_t)s, s0, P0, C0, s1, P1, C1, ws_bwd, PB, gamma, film, film_ld,
+                     coef_p, coef_q, HW, G, eps);
+  PMI_CHECK_LAUNCH();
+  return PMI_OK;
+}
+extern "C" int pmi_gn_bwd_apply(const void* x, const void* x1, int C0, const void* dy, const float* coef_a, const float* coef_b, const float* coef_p,
+                                const float* coef_q, int act, const void* gadd0, const void* gadd1, void* dx0, void* dx1, int N, int HW, int C,
+                                int dtype, pmi_stream_t s) {
+  if (!x || !dy || !coef_a || !coef_b || !coef_p || !coef_q || !dx0 || N <= 0 || HW <= 0 || C <= 0 || (C & 7) || (C0 & 7) || C0 > C ||
+      (C0 < C && (!x1 || !dx1)) || dtype == PMI_DT_F16X2)
+    return PMI_ERR_ARG;
+  const int64_t total = (int64_t)N * HW * (C / 8);
+  const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+  hipStream_t st = (hipStream_t)s;
+  if (dtype == PMI_DT_BF16) hipLaunchKernelGGL(gn_bwd_apply_kernel<BF16>, dim3(blocks), dim3(256), 0, st, (const u16*)x, (const u16*)x1, C0, (const u16*)dy, coef_a, coef_b, coef_p, coef_q, act, (const u16*)gadd0, (const u16*)gadd1, (u16*)dx0, (u16*)dx1, N, HW, C);
+  else hipLaunchKernelGGL(gn_bwd_apply_kernel<F16>, dim3(blocks), dim3(256), 0, st, (const u16*)x, (const u16*)x1, C0, (const u16*)dy, coef_a, coef_b, coef_p, coef_q, act, (const u16*)gadd0, (const u16*)gadd1, (u16*)dx0, (u16*)dx1, N, HW, C);
   PMI_CHECK_LAUNCH();
   return PMI_OK;
 }

@@ -503,6 +503,52 @@ def _gn_coeffs(x, x1, gamma, beta, groups, dt, film, film_ld, eps):
     return ca, cb
 
 
+def group_norm_coeffs_train(x: torch.Tensor, gamma, beta, groups: int, dt: int, *, x1: Optional[torch.Tensor] = None,
+                            film: Optional[torch.Tensor] = None, film_ld: int = 0, eps: float = 1e-5):
+    """As group_norm_coeffs, also returning the per-channel (sum, sumsq) partials the coefficients came from, as the argument tuple
+    (s0, P0, C0, s1, P1, C1) of pmi_gn_finalize / pmi_gn_bwd_finalize: the backward recomputes the forward moments from them."""
+    n, h, w, _ = x.shape
+    c0 = logical_c(x, dt)
+    c1 = logical_c(x1, dt) if x1 is not None else 0
+    c, hw, dev = c0 + c1, h * w, x.device
+    ca, cb = _empty((n, c), torch.float32, dev), _empty((n, c), torch.float32, dev)
+    st0 = getattr(x, "_pmi_stats", None)
+    st1 = getattr(x1, "_pmi_stats", None) if x1 is not None else None
+    if st0 is not None and (x1 is None or st1 is not None):
+        parts = (st0[0], st0[1], c0, st1[0] if st1 else None, st1[1] if st1 else 0, c1)
+    else:
+        nchunk = max(1, min(hw // 8, (1024 + n - 1) // n))
+        ws = _empty((n, nchunk, c, 2), torch.float32, dev)
+        call("pmi_gn_stats", ptr(x), ptr(x1), c0, ptr(ws), n, hw, c, groups, nchunk, dt)
+        parts = (ws, nchunk, c, None, 0, 0)
+    call("pmi_gn_finalize", ptr(parts[0]), parts[1], parts[2], ptr(parts[3]), parts[4], parts[5], ptr(gamma), ptr(beta), ptr(film), film_ld,
+         ptr(ca), ptr(cb), n, hw, groups, eps)
+    return ca, cb, parts
+
+
+def group_norm_backward(x: torch.Tensor, dy: torch.Tensor, ca, cb, parts, gamma, groups: int, dt: int, *, x1: Optional[torch.Tensor] = None,
+                        film: Optional[torch.Tensor] = None, film_ld: int = 0, act: int = ACT_NONE, gadd0: Optional[torch.Tensor] = None,
+                        gadd1: Optional[torch.Tensor] = None, eps: float = 1e-5):
+    """Gradient wrt x (and x1) of y = act(GroupNorm(cat(x, x1)) * gamma [FiLM] + beta) given dy = d loss / d y [N, H, W, C] (one tensor over the
+    concat) -- pmi_gn_bwd_stats / _finalize / _apply; gadd0 / gadd1: gradients arriving over another path, added on the way out.
+    Returns (dx, dx1)."""
+    n, h, w, c0 = x.shape
+    c1 = x1.shape[-1] if x1 is not None else 0
+    c, hw, dev = c0 + c1, h * w, x.device
+    assert dy.shape[-1] == c and dy.is_contiguous() and x.is_contiguous() and (x1 is None or x1.is_contiguous())
+    nchunk = max(1, min(hw // 8, (1024 + n - 1) // n))
+    wsb = _empty((n, nchunk, c, 2), torch.float32, dev)
+    call("pmi_gn_bwd_stats", ptr(x), ptr(x1), c0, ptr(dy), ptr(ca), ptr(cb), act, ptr(wsb), n, hw, c, nchunk, dt)
+    cp, cq = _empty((n, c), torch.float32, dev), _empty((n, c), torch.float32, dev)
+    call("pmi_gn_bwd_finalize", ptr(parts[0]), parts[1], parts[2], ptr(parts[3]), parts[4], parts[5], ptr(wsb), nchunk, ptr(gamma), ptr(film), film_ld,
+         ptr(cp), ptr(cq), n, hw, groups, eps)
+    dx0 = torch.empty_like(x)
+    dx1 = torch.empty_like(x1) if x1 is not None else None
+    call("pmi_gn_bwd_apply", ptr(x), ptr(x1), c0, ptr(dy), ptr(ca), ptr(cb), ptr(cp), ptr(cq), act, ptr(gadd0), ptr(gadd1), ptr(dx0), ptr(dx1),
+         n, hw, c, dt)
+    return dx0, dx1
+
+
 def group_norm_coeffs(x: torch.Tensor, gamma, beta, groups: int, dt: int, *, x1: Optional[torch.Tensor] = None,
                       film: Optional[torch.Tensor] = None, film_ld: int = 0, eps: float = 1e-5):
     """Per-(sample, channel) coefficients (a, b) with norm(x)*gamma+beta[FiLM] = x*a+b (no apply pass)."""

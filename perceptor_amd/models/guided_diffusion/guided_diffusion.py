@@ -36,6 +36,22 @@ WeightStore = ParamTree      # frozen reference-named parameters as a module tre
 _CONFIGS = {"standard": (adm.openimages_config, (3, 512, 512)), "pixelart": (adm.pixelart_config, (3, 256, 256))}
 
 
+class _PredictedNoise(torch.autograd.Function):
+    """predicted_noise(x, t) with an input gradient, as autograd provides upstream (the UNet is an nn.Module there): forward and backward are
+    the HIP engine's forward_train / backward (engine/adm.py).  Weights are frozen: no parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, diffused, idx, model):
+        eps, tape = model.engine.forward_train(diffused, idx, model.model.state_dict(), out_channels=3)
+        ctx.model, ctx.tape = model, tape
+        return eps
+
+    @staticmethod
+    def backward(ctx, grad_eps):
+        m = ctx.model
+        return m.engine.backward(ctx.tape, grad_eps.contiguous(), m.model.state_dict()), None, None
+
+
 class GuidedDiffusion(torch.nn.Module):
     def __init__(self, name="standard", *, weights="synthetic", checkpoint: Optional[str] = None, dtype="bf16", seed=0,
                  config: Optional[adm.AdmConfig] = None):
@@ -146,10 +162,13 @@ class GuidedDiffusion(torch.nn.Module):
         if idx.numel() == 1 and n > 1:
             idx = idx.expand(n)
         if torch.is_grad_enabled() and diffused_images.requires_grad:
-            # upstream this call is differentiable (guided_diffusion.py:125-133: autocast, no no_grad); the HIP ADM engine has no input-gradient
-            # pass yet, and returning a detached eps would hand the caller None gradients without a word
-            raise NotImplementedError("GuidedDiffusion.predicted_noise: gradients to diffused_images are not implemented for the ADM UNet engine; "
-                                      "call it under torch.no_grad() or pass diffused_images.detach() (VelocityDiffusion supports the gradient)")
+            # upstream this call is differentiable (guided_diffusion.py:125-133: autocast, no no_grad; the blocks run through
+            # CheckpointFunction, nn.py:138-189): the engine's training-mode forward + tape backward give the same input gradient
+            eng = self._need_engine()
+            if getattr(eng, "precise", False):
+                raise NotImplementedError("GuidedDiffusion.predicted_noise: the input gradient runs in the 16-bit modes (dtype='bf16' / 'f16'); "
+                                          "call it under torch.no_grad() or pass diffused_images.detach() in the precise / mixed modes")
+            return _PredictedNoise.apply(diffused_images.to(self.device), idx, self)
         return self._need_engine().forward(diffused_images.to(self.device), idx, out_channels=3)
 
     def predictions(self, diffused_images, indices) -> Predictions:

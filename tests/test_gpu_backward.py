@@ -241,3 +241,122 @@ def test_guided_resample_matches_autograd_chain_over_the_oracle():
           f"guidance step {float((eps_ref - eps_g).abs().max()):.3f}")
     assert frac >= 0.98
     assert float(loss.noise.grad.abs().max()) == 0.0                                   # zeroed at the end, as upstream
+
+
+# ---- ADM UNet (GuidedDiffusion) input gradient, round 3 -----------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", [dict(c0=64, c1=0, film=True, act=2), dict(c0=64, c1=32, film=False, act=2), dict(c0=96, c1=0, film=False, act=0)])
+def test_group_norm32_backward_vs_autograd(case, dtype):
+    """pmi_gn_bwd_stats / _finalize / _apply against torch autograd of act(GroupNorm32(cat(x, x1)) * gamma (1 + scale) + beta' ...), one and two
+    sources, with FiLM, with the gradient arriving over a second path added on the way out."""
+    from perceptor_amd._hip import dtype_code
+    from perceptor_amd.engine import ops
+    dt = dtype_code("bf16" if dtype == torch.bfloat16 else "f16")
+    g = torch.Generator().manual_seed(5)
+    n, h, w, c0, c1 = 2, 12, 16, case["c0"], case["c1"]
+    c = c0 + c1
+    x = (torch.randn(n, c, h, w, generator=g) * 1.5 + 0.3).to(dtype).float().requires_grad_()
+    gamma, beta = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    film = 0.2 * torch.randn(n, 2 * c, generator=g) if case["film"] else None
+    y = F.group_norm(x, 32, gamma, beta, eps=1e-5)
+    if film is not None:
+        y = y * (1 + film[:, :c, None, None]) + film[:, c:, None, None]
+    if case["act"] == 2:
+        y = F.silu(y)
+    dy = torch.randn(n, c, h, w, generator=g).to(dtype).float()
+    extra = torch.randn(n, c, h, w, generator=g).to(dtype).float()
+    (ref,) = torch.autograd.grad((y * dy).sum() + (x * extra).sum(), x)
+    xd = _nhwc16(x.detach(), dtype)
+    x0, x1 = (xd[..., :c0].contiguous(), xd[..., c0:].contiguous()) if c1 else (xd, None)
+    ed = _nhwc16(extra, dtype)
+    e0, e1 = (ed[..., :c0].contiguous(), ed[..., c0:].contiguous()) if c1 else (ed, None)
+    filmd = film.to(DEV) if film is not None else None
+    ca, cb, parts = ops.group_norm_coeffs_train(x0, gamma.to(DEV), beta.to(DEV), 32, dt, x1=x1, film=filmd, film_ld=2 * c if film is not None else 0)
+    dx0, dx1 = ops.group_norm_backward(x0, _nhwc16(dy, dtype), ca, cb, parts, gamma.to(DEV), 32, dt, x1=x1, film=filmd,
+                                       film_ld=2 * c if film is not None else 0, act=case["act"], gadd0=e0, gadd1=e1)
+    got = torch.cat([dx0, dx1], dim=-1) if c1 else dx0
+    got = got.float().cpu().permute(0, 3, 1, 2)
+    tol = 2 ** (-6 if dtype == torch.bfloat16 else -9) * float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= tol, (float((got - ref).abs().max()), tol)
+
+
+ADM_TINY = {
+    "a": dict(image_size=64, model_channels=32, num_res_blocks=1, channel_mult=(1, 2, 2), attention_ds=(2, 4),
+              num_head_channels=16, use_scale_shift_norm=True, resblock_updown=True),
+    "b": dict(image_size=64, model_channels=32, num_res_blocks=2, channel_mult=(1, 2), attention_ds=(2,),
+              num_heads=2, use_new_attention_order=True),
+}
+
+
+def _adm_grad(cfg_kw, dtype, x, t, probe, standard=False):
+    from perceptor_amd.engine import adm
+    from perceptor_amd.utils.synth import synth_state_dict
+    cfg = adm.openimages_config() if standard else adm.AdmConfig(**cfg_kw)
+    sd = synth_state_dict(adm.state_dict_shapes(cfg), 0)
+    eng = adm.AdmEngine(cfg, sd, DEV, dtype)
+    img = ((x + 1) / 2).to(DEV)
+    y, tape = eng.forward_train(img, t.to(DEV), sd, out_channels=3)
+    y_inf = eng.forward(img, t.to(DEV), out_channels=3)
+    assert float((y - y_inf).abs().max()) <= 1e-6 + 2e-2 * float(y_inf.abs().max())      # the tape forward is the inference forward (attention path aside)
+    g_img = eng.backward(tape, probe.to(DEV), sd)
+    return g_img.cpu() / 2.0, y.cpu()          # d / d x with x = 2 img - 1
+
+
+@pytest.mark.parametrize("dtype,tol_l2,tol_cos", [("bf16", 8e-2, 0.997), ("f16", 2e-2, 0.9998)])
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_adm_tiny_input_gradient_vs_reference_autograd(tag, dtype, tol_l2, tol_cos):
+    """Both tiny configs (both attention orders and ResBlock flavours, up / down ResBlocks, FiLM and additive timestep conditioning) against
+    the gradient the REFERENCE's autograd produced (tests/golden/adm_tiny_*_grad.npz).  No ReLU masks on this path (SiLU is smooth), so the
+    bounds are tighter than the v-diffusion nets': the error is the 16-bit rounding of ~60 layers forward and back."""
+    from perceptor_amd.utils.synth import seeded_noise
+    g0 = golden(f"adm_tiny_{tag}_grad")
+    x = seeded_noise((2, 3, 64, 64), 31)
+    probe = seeded_noise((2, 3, 64, 64), 61)
+    got, _ = _adm_grad(ADM_TINY[tag], dtype, x, g0["t"], probe)
+    rel, cos = _rel(got, g0["g"]), _cos(got, g0["g"])
+    print(f"[grad] adm_tiny_{tag} {dtype}: rel-L2 {rel:.3e} cos {cos:.6f}")
+    assert rel <= tol_l2 and cos >= tol_cos, (rel, cos)
+
+
+@pytest.mark.parametrize("dtype,tol_l2,tol_cos", [("bf16", 1e-1, 0.995), ("f16", 3e-2, 0.9995)])
+def test_adm_standard_128_input_gradient_vs_reference_autograd(dtype, tol_l2, tol_cos):
+    """The shipped 558 M-parameter net at 128x128 (64-channel heads: the flash attention backward) vs the reference's autograd."""
+    from perceptor_amd.utils.synth import seeded_noise
+    g0 = golden("adm_standard_128_grad")
+    x = seeded_noise((1, 3, 128, 128), 32)
+    probe = seeded_noise((1, 3, 128, 128), 62)
+    got, _ = _adm_grad(None, dtype, x, g0["t"], probe, standard=True)
+    sub = got[:, :, ::2, ::2]
+    rel, cos = _rel(sub, g0["g_sub"]), _cos(sub, g0["g_sub"])
+    print(f"[grad] adm_standard_128 {dtype}: rel-L2 {rel:.3e} cos {cos:.6f}")
+    assert rel <= tol_l2 and cos >= tol_cos, (rel, cos)
+    f = got.flatten(1).double()
+    assert abs(float(f.norm()) / float(g0["g_mom"][0, 2]) - 1) < 5e-2
+
+
+def test_guided_diffusion_predicted_noise_is_differentiable():
+    """models.GuidedDiffusion.predicted_noise(x.requires_grad_()) backpropagates like upstream (guided_diffusion.py:125-133); under no_grad or
+    with a detached input it is the plain inference call; the precise / mixed modes raise instead of returning a detached tensor."""
+    from perceptor_amd import models
+    from perceptor_amd.engine import adm
+    cfg = adm.AdmConfig(**ADM_TINY["a"])
+    m = models.GuidedDiffusion(config=cfg, dtype="f16").to(DEV)
+    img = (torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(1))).to(DEV).requires_grad_()
+    eps = m.predicted_noise(img, torch.tensor([300, 20]))
+    assert eps.requires_grad
+    w = torch.randn(eps.shape, generator=torch.Generator().manual_seed(2)).to(DEV)
+    (gr,) = torch.autograd.grad((eps * w).sum(), img)
+    assert gr.shape == img.shape and torch.isfinite(gr).all() and float(gr.abs().max()) > 0
+    # directional derivative: <grad, d> ~ (L(x + h d) - L(x - h d)) / 2h
+    d = torch.randn(img.shape, generator=torch.Generator().manual_seed(3)).to(DEV)
+    hstep = 2e-2
+    with torch.no_grad():
+        lp = (m.predicted_noise(img + hstep * d, torch.tensor([300, 20])) * w).sum()
+        lm = (m.predicted_noise(img - hstep * d, torch.tensor([300, 20])) * w).sum()
+    fd, an = float((lp - lm) / (2 * hstep)), float((gr * d).sum())
+    assert abs(fd - an) <= 0.1 * abs(an) + 0.5, (fd, an)
+    with torch.no_grad():
+        assert not m.predicted_noise(img, 300).requires_grad
+    mp = models.GuidedDiffusion(config=cfg, dtype="precise").to(DEV)
+    with pytest.raises(NotImplementedError):
+        mp.predicted_noise(img, 300)

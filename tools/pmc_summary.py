@@ -25,11 +25,25 @@ def per_kernel(path, counter):
     return agg
 
 
+def kernel_src_sha16():
+    """Identity of the kernels the HBM figures belong to: bench.py reports `roofline.traffic` from this file only while the conv sources are unchanged."""
+    import hashlib
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "perceptor_amd", "csrc")
+    h = hashlib.sha256()
+    for n in ("conv_wd.hip", "conv3x3.hip", "common.h"):
+        with open(os.path.join(root, n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def main():
     fetch, write, out = sys.argv[1:4]
     fa, wa = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
     res = {"_note": "per-launch means over one `bench.py --steps 2 --warmup 1` run per counter; KiB as reported; "
-                    "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE x2 correction)"}
+                    "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE x2 correction)",
+           "_kernel_src_sha16": kernel_src_sha16()}
+    res["_bench_args"] = sys.argv[4] if len(sys.argv) > 4 else ""
     for k in sorted(set(fa) | set(wa), key=lambda k: -(2 * sum(fa.get(k, [0])) + sum(wa.get(k, [0])))):
         f, w = fa.get(k, []), wa.get(k, [])
         fm = sum(f) / len(f) if f else 0.0
@@ -38,7 +52,7 @@ def main():
                   "hbm_bytes_per_launch": round((2 * fm + wm) * 1024)}
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
-    print(json.dumps({k: v for k, v in list(res.items())[:6]}, indent=1))
+    print(json.dumps({k: v for k, v in list(res.items())[:8]}, indent=1))
 
 
 if __name__ == "__main__":
