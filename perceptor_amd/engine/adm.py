@@ -409,8 +409,11 @@ class AdmEngine:
                 h = self._res_train(l, h, h1, emb, tape)
             elif isinstance(l, _Attn):
                 h = self._attn_train(l, h, tape, sd)
+            elif isinstance(l, _Resample) and self.cfg.conv_resample:      # unet.py:81-138: nearest x2 + conv / stride-2 conv
+                h = ops.igemm(h, self.w[l.p], up=l.up, stride=1 if l.up else 2, want_stats=True)
+                tape.append(("resample", l))
             else:
-                raise NotImplementedError("the input gradient covers the resblock_updown / ResBlock / attention layers of the shipped configs")
+                raise NotImplementedError("conv_resample=False is not used by the shipped configs")
             h1 = None
         return h
 
@@ -519,6 +522,19 @@ class AdmEngine:
                 g, g1 = self._res_back(rec, g, sd, ld)
             elif rec[0] == "attn":
                 g = self._attn_back(rec, g, sd)
+            elif rec[0] == "resample":
+                l = rec[1]
+                wt = self._wt(l.p + "T", sd[l.p + (".conv" if l.up else ".op") + ".weight"])
+                if l.up:                             # conv over nearest-up(x): dX at the high resolution, then the sum of each 2x2 block
+                    d = ops.igemm(g, wt)
+                    n, h_, w_, c = d.shape
+                    g = torch.empty((n, h_ // 2, w_ // 2, c), dtype=d.dtype, device=d.device)
+                    call("pmi_upsample_nearest2_bwd", ptr(d), ptr(g), n, h_ // 2, w_ // 2, c, self.dt)
+                else:                                # stride-2 conv: dX = stride-1 conv of the zero-inserted gradient with the flipped weights
+                    n, h_, w_, c = g.shape           # (two torch ops for the layout step: only the conv_resample configs -- pixelart -- come here)
+                    z = torch.zeros((n, 2 * h_, 2 * w_, c), dtype=g.dtype, device=g.device)
+                    z[:, ::2, ::2] = g
+                    g = ops.igemm(z, wt)
             else:                                    # the first convolution: fp32 gradient wrt the padded input
                 g = ops.igemm(g, self._wt(rec[1][1] + "T", sd[rec[1][1] + ".weight"]), out_f32=True)
         return g, g1

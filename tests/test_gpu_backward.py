@@ -302,7 +302,7 @@ def _adm_grad(cfg_kw, dtype, x, t, probe, standard=False):
     return g_img.cpu() / 2.0, y.cpu()          # d / d x with x = 2 img - 1
 
 
-@pytest.mark.parametrize("dtype,tol_l2,tol_cos", [("bf16", 8e-2, 0.997), ("f16", 2e-2, 0.9998)])
+@pytest.mark.parametrize("dtype,tol_l2,tol_cos", [("bf16", 4e-2, 0.999), ("f16", 6e-3, 0.99995)])      # measured 1.1-1.9e-2 / 0.9998, 1.4-2.4e-3 / 0.999997
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_adm_tiny_input_gradient_vs_reference_autograd(tag, dtype, tol_l2, tol_cos):
     """Both tiny configs (both attention orders and ResBlock flavours, up / down ResBlocks, FiLM and additive timestep conditioning) against
@@ -318,7 +318,7 @@ def test_adm_tiny_input_gradient_vs_reference_autograd(tag, dtype, tol_l2, tol_c
     assert rel <= tol_l2 and cos >= tol_cos, (rel, cos)
 
 
-@pytest.mark.parametrize("dtype,tol_l2,tol_cos", [("bf16", 1e-1, 0.995), ("f16", 3e-2, 0.9995)])
+@pytest.mark.parametrize("dtype,tol_l2,tol_cos", [("bf16", 3e-2, 0.9995), ("f16", 4e-3, 0.99999)])       # measured 1.14e-2 / 0.99994, 1.42e-3 / 0.999999
 def test_adm_standard_128_input_gradient_vs_reference_autograd(dtype, tol_l2, tol_cos):
     """The shipped 558 M-parameter net at 128x128 (64-channel heads: the flash attention backward) vs the reference's autograd."""
     from perceptor_amd.utils.synth import seeded_noise
@@ -347,14 +347,12 @@ def test_guided_diffusion_predicted_noise_is_differentiable():
     w = torch.randn(eps.shape, generator=torch.Generator().manual_seed(2)).to(DEV)
     (gr,) = torch.autograd.grad((eps * w).sum(), img)
     assert gr.shape == img.shape and torch.isfinite(gr).all() and float(gr.abs().max()) > 0
-    # directional derivative: <grad, d> ~ (L(x + h d) - L(x - h d)) / 2h
-    d = torch.randn(img.shape, generator=torch.Generator().manual_seed(3)).to(DEV)
-    hstep = 2e-2
-    with torch.no_grad():
-        lp = (m.predicted_noise(img + hstep * d, torch.tensor([300, 20])) * w).sum()
-        lm = (m.predicted_noise(img - hstep * d, torch.tensor([300, 20])) * w).sum()
-    fd, an = float((lp - lm) / (2 * hstep)), float((gr * d).sum())
-    assert abs(fd - an) <= 0.1 * abs(an) + 0.5, (fd, an)
+    # the class surface is the engine's forward_train / backward (whose gradient the tests above pin on the reference's autograd)
+    eng = m.engine
+    idx = torch.tensor([300, 20]).to(DEV)
+    _, tape = eng.forward_train(img.detach(), idx, m.model.state_dict(), out_channels=3)
+    want = eng.backward(tape, w, m.model.state_dict())
+    assert torch.equal(gr, want)
     with torch.no_grad():
         assert not m.predicted_noise(img, 300).requires_grad
     mp = models.GuidedDiffusion(config=cfg, dtype="precise").to(DEV)
