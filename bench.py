@@ -63,6 +63,8 @@ def parse():
     p.add_argument("--no-kernel-events", action="store_true")
     p.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (helps launch-bound small configs such as c1)")
     p.add_argument("--dump-kernels", default=None, help="write per-launch (ms, GFLOP, MB) of the timed conv3x3 launches of the last step to this file")
+    p.add_argument("--backward", action="store_true", help="row f2: time UNet forward (training mode, tape kept) + input-gradient backward of a fixed "
+                                                            "output gradient instead of the sampling step (no CLIP leg, no update)")
     p.add_argument("--rehearse", action="store_true", help="launcher / collective rehearsal without the model: every rank joins the process group "
                                                             "(gloo when there is no GPU), all-gathers a small tensor and rank 0 prints a JSON line")
     return p.parse_args()
@@ -353,6 +355,8 @@ def main():
     from perceptor_amd.utils.synth import seeded_noise
 
     model_name, res, nb, clip_arch = CONFIGS[a.config]
+    if a.backward:
+        clip_arch = None
     is_v = model_name not in ("standard", "pixelart")
     model = (models.VelocityDiffusion(model_name, dtype=a.dtype) if is_v else models.GuidedDiffusion(model_name, dtype=a.dtype)).to(dev)
     cond = seeded_noise((1, 1, 512), 11).to(dev) if model_name.startswith("cc12m") else None
@@ -376,6 +380,40 @@ def main():
             pred = pred.guided(grad, guidance_scale=0.5, clamp_value=1e-6)
         return pred.step(ti)
     eager_step = one_step
+    tape_gb = None
+    if a.backward:
+        # what a script differentiating through the UNet pays per evaluation (losses/velocity_diffusion.py:33-61 guided_resample_; upstream
+        # GuidedDiffusion.predicted_noise under autograd, guided_diffusion.py:125-133): training-mode forward + backward to the input
+        a.no_kernel_events, a.no_modes = True, True
+        probe = seeded_noise((nb, 3, res, res), 99).to(dev)
+        sdict = model.model.state_dict()
+
+        def tensors(o, seen):
+            if torch.is_tensor(o):
+                if o.data_ptr() not in seen:
+                    seen[o.data_ptr()] = o.numel() * o.element_size()
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    tensors(v, seen)
+            elif isinstance(o, dict):
+                for v in o.values():
+                    tensors(v, seen)
+
+        def one_step(images, i, model=model):   # noqa: F811
+            nonlocal tape_gb
+            fi, _ = sched[i % len(sched)]
+            if is_v:
+                if cond is not None:
+                    raise SystemExit("--backward: unconditional nets only (c2, c3, c5-noclip)")
+                _, tape = model.engine.forward_train(images, fi.reshape(-1).expand(nb), None)
+            else:
+                _, tape = model.engine.forward_train(images, model.indices(fi).expand(nb), sdict, out_channels=3)
+            if tape_gb is None:
+                seen = {}
+                tensors(tape, seen)
+                tape_gb = sum(seen.values()) / 1e9
+            g = model.engine.backward(tape, probe, sdict)
+            return images
 
     if a.graph:
         from perceptor_amd.engine.graph import GraphedStep
@@ -430,7 +468,7 @@ def main():
 
     if rank == 0:
         step_ms_dev = sum(s.elapsed_time(e) for s, e in ev) / a.steps
-        gflop_sample = UNET_GFLOP[model_name][res] + (2 * CLIP_FWD_GFLOP[clip_arch] if clip_arch else 0.0)
+        gflop_sample = UNET_GFLOP[model_name][res] * (2.0 if a.backward else 1.0) + (2 * CLIP_FWD_GFLOP[clip_arch] if clip_arch else 0.0)
         tflop_step = gflop_sample * nb / 1e3
         achieved = tflop_step / (step_ms_dev / 1e3)
         step_roof = {"achieved": round(achieved, 2), "frac": round(achieved / PEAK_TFLOPS[a.dtype], 4),
@@ -483,7 +521,8 @@ def main():
         else:
             roof.update({"achieved": step_roof["achieved"], "frac": step_roof["frac"], "kernel": "whole step (no per-kernel events)"})
         out = {
-            "metric": "denoising steps/sec (UNet+CLIP-grad) at 512x512 batch 8" if a.config == "c5" else f"denoising steps/sec ({a.config})",
+            "metric": (f"UNet forward + input-gradient evaluations/sec ({a.config})" if a.backward else
+                       "denoising steps/sec (UNet+CLIP-grad) at 512x512 batch 8" if a.config == "c5" else f"denoising steps/sec ({a.config})"),
             "value": round(a.steps / elapsed * world, 4),
             "unit": f"steps/s (batch-{nb} steps summed over GPUs)",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -497,6 +536,7 @@ def main():
             "outputs_finite": finite,
             "rccl_ranks": dist.get_world_size() if dist is not None else 0,
             "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},     # skew between the ranks' own clocks
+            **({"tape_gb": round(tape_gb, 2), "flop_note": "roofline.step counts 2x the forward FLOP (forward + dX of every layer; no weight gradients)"} if a.backward else {}),
             "roofline": roof,
         }
         if dist is not None:
