@@ -382,7 +382,7 @@ def igemm(a0: torch.Tensor, lin: PackedLinear, *, a1: Optional[torch.Tensor] = N
             st = _empty((m // a.hw, rows, lin.n_p, 2), torch.float32, a0.device)
             a.stats, a.stats_p = ptr(st), rows
             out._pmi_stats = (st, rows)
-    if DEBUG_WS is not None:
+    if DEBUG_WS is not None and a.splitk <= 1:      # (a split-K call's ws is its slab workspace: the phase stamps of the probes are for unsplit calls only)
         a.ws = ptr(DEBUG_WS)
         a.reserved = 77
     if KERNEL_EVENTS is not None and lin.taps == 9 and HALO_ENABLED and _hip.lib().pmi_conv3x3_halo_config(C.byref(a)) >= 0:

@@ -42,14 +42,17 @@ class _PredictedNoise(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, diffused, idx, model):
-        eps, tape = model.engine.forward_train(diffused, idx, model.model.state_dict(), out_channels=3)
+        eng = model.grad_engine
+        eps, tape = eng.forward_train(diffused, idx, model.model.state_dict(), out_channels=3)
+        if eng is not model.engine:          # mixed / precise model: the VALUE is that mode's, the tape (and so the gradient) the f16 engine's
+            eps = model.engine.forward(diffused, idx, out_channels=3)
         ctx.model, ctx.tape = model, tape
         return eps
 
     @staticmethod
     def backward(ctx, grad_eps):
         m = ctx.model
-        return m.engine.backward(ctx.tape, grad_eps.contiguous(), m.model.state_dict()), None, None
+        return m.grad_engine.backward(ctx.tape, grad_eps.contiguous(), m.model.state_dict()), None, None
 
 
 class GuidedDiffusion(torch.nn.Module):
@@ -83,7 +86,7 @@ class GuidedDiffusion(torch.nn.Module):
         self.schedule_alphas = torch.nn.Parameter(torch.from_numpy(ac).sqrt().float(), requires_grad=False)
         self.schedule_sigmas = torch.nn.Parameter((1 - torch.from_numpy(ac)).sqrt().float(), requires_grad=False)
         self._engine: Optional[adm.AdmEngine] = None
-        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_engine", None))
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._drop_engines())
 
     @property
     def engine(self) -> Optional[adm.AdmEngine]:
@@ -97,8 +100,24 @@ class GuidedDiffusion(torch.nn.Module):
                 self._engine = adm.AdmEngine(self.config, self.model.state_dict(), self.device, self.compute_dtype)
         return self._engine
 
-    def _apply(self, fn, *a, **k):          # .to() / .cuda() / .cpu() / .float() ... all come through here
+    @property
+    def grad_engine(self):
+        """The engine whose training-mode forward + backward give the input gradient: the model's own in the 16-bit modes; a lazily built f16
+        engine for the mixed / precise modes (their split tensors have no backward kernels: the gradient is then the f16 path's, 1.4e-3
+        relative to fp32 autograd on the shipped net, tests/test_gpu_backward.py -- the forward value stays the mode's own)."""
+        eng = self.engine
+        if eng is None or not getattr(eng, "precise", False):
+            return eng
+        if self.__dict__.get("_grad_engine") is None:
+            self.__dict__["_grad_engine"] = adm.AdmEngine(self.config, self.model.state_dict(), self.device, "f16")
+        return self.__dict__["_grad_engine"]
+
+    def _drop_engines(self) -> None:
         self._engine = None
+        self.__dict__["_grad_engine"] = None
+
+    def _apply(self, fn, *a, **k):          # .to() / .cuda() / .cpu() / .float() ... all come through here
+        self._drop_engines()
         return super()._apply(fn, *a, **k)
 
     def to(self, *args, **kwargs):
@@ -164,10 +183,7 @@ class GuidedDiffusion(torch.nn.Module):
         if torch.is_grad_enabled() and diffused_images.requires_grad:
             # upstream this call is differentiable (guided_diffusion.py:125-133: autocast, no no_grad; the blocks run through
             # CheckpointFunction, nn.py:138-189): the engine's training-mode forward + tape backward give the same input gradient
-            eng = self._need_engine()
-            if getattr(eng, "precise", False):
-                raise NotImplementedError("GuidedDiffusion.predicted_noise: the input gradient runs in the 16-bit modes (dtype='bf16' / 'f16'); "
-                                          "call it under torch.no_grad() or pass diffused_images.detach() in the precise / mixed modes")
+            self._need_engine()
             return _PredictedNoise.apply(diffused_images.to(self.device), idx, self)
         return self._need_engine().forward(diffused_images.to(self.device), idx, out_channels=3)
 

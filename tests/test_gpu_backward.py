@@ -336,7 +336,7 @@ def test_adm_standard_128_input_gradient_vs_reference_autograd(dtype, tol_l2, to
 
 def test_guided_diffusion_predicted_noise_is_differentiable():
     """models.GuidedDiffusion.predicted_noise(x.requires_grad_()) backpropagates like upstream (guided_diffusion.py:125-133); under no_grad or
-    with a detached input it is the plain inference call; the precise / mixed modes raise instead of returning a detached tensor."""
+    with a detached input it is the plain inference call; the precise / mixed modes return their own value and the f16 engine's gradient."""
     from perceptor_amd import models
     from perceptor_amd.engine import adm
     cfg = adm.AdmConfig(**ADM_TINY["a"])
@@ -355,6 +355,11 @@ def test_guided_diffusion_predicted_noise_is_differentiable():
     assert torch.equal(gr, want)
     with torch.no_grad():
         assert not m.predicted_noise(img, 300).requires_grad
+    # precise (and mixed) models: the value is the mode's own, the gradient the f16 engine's (lazily built twin)
     mp = models.GuidedDiffusion(config=cfg, dtype="precise").to(DEV)
-    with pytest.raises(NotImplementedError):
-        mp.predicted_noise(img, 300)
+    img2 = img.detach().clone().requires_grad_()
+    eps_p = mp.predicted_noise(img2, torch.tensor([300, 20]))
+    with torch.no_grad():
+        assert torch.equal(eps_p.detach(), mp.predicted_noise(img2.detach(), torch.tensor([300, 20])))
+    (gp,) = torch.autograd.grad((eps_p * w).sum(), img2)
+    assert torch.equal(gp, gr)
