@@ -441,7 +441,9 @@ def fused_mlp_epilogues(lin: PackedLinear, m: int) -> bool:
     """True when a plain 16-bit-output GEMM of m rows with these weights runs in the weights-direct kernel UNSPLIT, whose epilogue can also
     write the pre-activation value (pre_out) and multiply by an activation gradient (act_grad_of).  The library decides (its split-K cost
     model and A/B options included): pmi_igemm rejects D2 / aux on any other route."""
-    if not (GEMM_WD_ENABLED and lin.taps == 1 and not lin.split and lin.n_p % 32 == 0 and lin.K % 32 == 0):
+    # the structural part keeps the choice independent of the batch a rank holds (fused and unfused epilogues round differently: a shard must
+    # reproduce its slice of the full-batch gradient, tests/test_gpu_clip.py): wide layers only, any m a ViT batch produces
+    if not (GEMM_WD_ENABLED and lin.taps == 1 and not lin.split and lin.n_p % 256 == 0 and lin.K % 128 == 0 and m >= 64):
         return False
     a = IgemmArgs()
     a.taps, a.stride, a.M, a.N, a.K, a.C0, a.batch, a.batch_inner, a.hw = 1, 1, m, lin.n_p, lin.K, lin.K, 1, 1, 1
