@@ -113,7 +113,7 @@ def test_tiny_net_input_gradient_vs_oracle_autograd(cond, dtype):
     assert rel <= (1e-1 if dtype == "bf16" else 4e-2) and cos >= (0.995 if dtype == "bf16" else 0.9995)
 
 
-@pytest.mark.parametrize("dtype", ["bf16"])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
 def test_yfcc2_full_input_gradient_vs_reference_autograd(dtype):
     from perceptor_amd import models
     from perceptor_amd.utils.synth import seeded_noise
@@ -127,7 +127,7 @@ def test_yfcc2_full_input_gradient_vs_reference_autograd(dtype):
     g_x = img.grad.cpu() / 2
     rel, cos = _rel(g_x[:, :, ::2, ::2], g["g_sub"]), _cos(g_x[:, :, ::2, ::2], g["g_sub"])
     print(f"[parity] yfcc_2@128 input gradient {dtype} vs reference autograd: rel-L2={rel:.3e}, cos={cos:.5f}")
-    assert rel <= 1e-1 and cos >= 0.995
+    assert (rel <= 1e-1 and cos >= 0.995) if dtype == "bf16" else (rel <= 5e-2 and cos >= 0.999)     # (f16: ~sqrt(1e-3) of the ReLU masks' neighbourhood flips)
     f = g_x.flatten(1).double()
     assert torch.allclose(f.norm(dim=1).float(), g["g_mom"][:, 2], rtol=5e-2)
 
