@@ -262,11 +262,11 @@ def gen_vdiff_grad_cc12m():
         p_.requires_grad_(False)
     x = seeded_noise((1, 3, 64, 64), 42).requires_grad_(True)
     t = torch.tensor([0.7])
-    ce = seeded_noise((1, 512), 43)
+    ce = seeded_noise((1, 512), 43).requires_grad_(True)         # (round 3: also d / d clip_embed -- upstream keeps the conditioning in the graph)
     probe = seeded_noise((1, 3, 64, 64), 47)
     v = m(x, t, ce)
-    (g,) = torch.autograd.grad((v * probe).sum(), x)
-    save("vdiff_cc12m_1_64_grad", t=t, g=g, v_mom=moments(v.detach()))
+    g, g_ce = torch.autograd.grad((v * probe).sum(), (x, ce))
+    save("vdiff_cc12m_1_64_grad", t=t, g=g, g_ce=g_ce, v_mom=moments(v.detach()))
 
 
 def gen_vdiff_grad_wikiart():

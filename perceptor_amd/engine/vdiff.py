@@ -162,7 +162,8 @@ class VDiffEngine:
         self.precise = dt == _hip.DT_F16X2
         f32 = lambda k: sd[k].detach().float().to(dev).contiguous()
         self.w: Dict[str, object] = {}
-        mods, off = [], [0]
+        mods, off, mod_keys = [], [0], []
+        self._mod_keys, self._dmod = mod_keys, None
         first = [True]
 
         def pack(l, p):
@@ -176,8 +177,10 @@ class VDiffEngine:
                     self.w[p + ".skip"] = PackedLinear(sd[p + ".skip.weight"], None, dt, dev, cin_pad=24 if l.cin == 19 else None, sources=l.srcs)
                 if self.cond:
                     l.mod1 = off[0]; mods.append(sd[p + ".main.2.layer.weight"].float()); off[0] += 2 * l.cmid
+                    mod_keys.append(p + ".main.2.layer.weight")
                     if not l.last:
                         l.mod2 = off[0]; mods.append(sd[p + ".main.6.layer.weight"].float()); off[0] += 2 * l.cout
+                        mod_keys.append(p + ".main.6.layer.weight")
             elif isinstance(l, Attn):
                 if spec.get("attn_norm", True):
                     self.w[p + ".gn"] = (f32(p + ".norm.weight"), f32(p + ".norm.bias"))
@@ -451,11 +454,72 @@ class VDiffEngine:
     def _film_norm_back(self, xpre, d, mod, off):
         """d (gradient wrt Modulation2d's output, ReLU mask already applied) -> gradient wrt the GroupNorm(1, C) input xpre."""
         n, hh, ww, c = xpre.shape
+        if self._dmod is not None:
+            self._cond_grad_layer(xpre, d, off)
         out = torch.empty_like(xpre)
         scale = mod[:, off:]                                                     # [N, >= C] view: (scale | shift) of this layer
         part = torch.empty((n, _hip.lib().pmi_gn1_bwd_partials(hh * ww, c), 4), dtype=torch.float64, device=xpre.device)
         call("pmi_gn1_bwd", ptr(xpre), ptr(d), scale.data_ptr(), mod.stride(0), 1.0, None, ptr(out), ptr(part), n, hh * ww, c, 1e-5, self.dt)
         return out
+
+    # ---- gradient to the conditioning (cc12m_1: upstream velocity_diffusion.py:96-109 lets autograd reach `conditioning`) -----------------
+    # Modulation2d (cc12m_1.py:33-43) is out = xhat * (1 + scale[n][c]) + shift[n][c] on xhat = GroupNorm(1, C)(x): with d = the (masked)
+    # gradient wrt out, d shift = sum_p d and d scale = sum_p d xhat = r (sum_p d x - mu sum_p d).  The per-channel sums are one streaming pass
+    # (pmi_gn_bwd_stats), the per-sample moments come from the forward statistics pass; all layers accumulate into one [N, sum 2C] row that
+    # goes back through the mapping network (four tiny fp32 GEMMs on the exact-fp32 MFMA, recomputed forward for the ReLU masks).
+    def _cond_grad_layer(self, xpre, d, off):
+        n, hh, ww, c = xpre.shape
+        hw, dev, dt = hh * ww, xpre.device, self.dt
+        nchunk = max(1, min(hw // 8, (1024 + n - 1) // n))
+        ws = torch.empty((n, nchunk, c, 2), dtype=torch.float32, device=dev)
+        call("pmi_gn_stats", ptr(xpre), None, c, ptr(ws), n, hw, c, 1, nchunk, dt)
+        fs = ws.double().sum(dim=(1, 2))                                   # [n, 2]: sum, sumsq over the sample (per-sample scalars: torch)
+        cnt = float(hw * c)
+        mu = fs[:, 0] / cnt
+        r = 1.0 / torch.sqrt((fs[:, 1] / cnt - mu * mu).clamp_min(0.0) + 1e-5)
+        one = torch.ones((n, c), dtype=torch.float32, device=dev)
+        zero = torch.zeros((n, c), dtype=torch.float32, device=dev)
+        wb = torch.empty((n, nchunk, c, 2), dtype=torch.float32, device=dev)
+        call("pmi_gn_bwd_stats", ptr(xpre), None, c, ptr(d), ptr(one), ptr(zero), ACT_NONE, ptr(wb), n, hw, c, nchunk, dt)
+        ab = wb.double().sum(dim=1)                                        # [n, c, 2]: sum_p d, sum_p d x
+        self._dmod[:, off:off + c] += (r[:, None] * (ab[..., 1] - mu[:, None] * ab[..., 0])).float()
+        self._dmod[:, off + c:off + 2 * c] += ab[..., 0].float()
+
+    def _mapping_back(self, t, clip_embed, d_mod, sd):
+        """d loss / d clip_embed from d loss / d (every layer's scale | shift): back through Modulation2d.layer, the two ResLinearBlocks
+        (cc12m_1.py:19-31, 121-124) and F.normalize(clip_embed) * sqrt(D) (cc12m_1.py:294).  fp32 throughout."""
+        dev = self.device
+        key = "_map_f32"
+        if key not in self.w:
+            f = lambda k: sd[k].detach().float().to(dev).contiguous()
+            self.w[key] = dict(w0=f("mapping.0.main.0.weight"), b0=f("mapping.0.main.0.bias"), w2=f("mapping.0.main.2.weight"), b2=f("mapping.0.main.2.bias"),
+                               ws=f("mapping.0.skip.weight"), v0=f("mapping.1.main.0.weight"), c0=f("mapping.1.main.0.bias"),
+                               v2=f("mapping.1.main.2.weight"), c2=f("mapping.1.main.2.bias"),
+                               mod=torch.cat([sd[k].detach().float() for k in self._mod_keys], 0).to(dev).contiguous())
+        m = self.w[key]
+        n = t.shape[0]
+        ce = clip_embed.to(device=dev, dtype=torch.float32).contiguous()
+        dim = ce.shape[1]
+        nrm = ce.norm(dim=1, keepdim=True).clamp_min(1e-12)
+        chat = ce / nrm
+        ff = torch.empty((n, 2 * self.mtw.numel()), dtype=torch.float32, device=dev)
+        call("pmi_fourier_features", ptr(t), ptr(self.mtw), ptr(ff), n, self.mtw.numel())
+        xin = torch.cat([chat * dim ** 0.5, ff], dim=1).contiguous()
+        ha = ops.linear_f32(xin, m["w0"], m["b0"], act=ACT_RELU)
+        u = ops.linear_f32(ha, m["w2"], m["b2"])                           # pre-ReLU of block 0's main path
+        z1 = torch.relu(u) + ops.linear_f32(xin, m["ws"], None)
+        hb = ops.linear_f32(z1.contiguous(), m["v0"], m["c0"], act=ACT_RELU)
+
+        def back(g, w):                                                     # g [n, out] @ w [out, in] -> [n, in]
+            out = torch.empty((n, w.shape[1]), dtype=torch.float32, device=dev)
+            return ops.gemm_f32(g.contiguous(), w, out, M=n, N=w.shape[1], K=w.shape[0], lda=g.shape[1], ldb=w.shape[1], ldd=w.shape[1], trans_b=True)
+
+        d_cond = back(d_mod, m["mod"])
+        d_z1 = back(back(d_cond, m["v2"]) * (hb > 0), m["v0"]) + d_cond
+        d_u = d_z1 * (u > 0)
+        d_xin = back(back(d_u, m["w2"]) * (ha > 0), m["w0"]) + back(d_z1, m["ws"])
+        d_cen = d_xin[:, :dim]
+        return (dim ** 0.5 / nrm) * (d_cen - chat * (chat * d_cen).sum(dim=1, keepdim=True))
 
     def _res_back(self, rec, g, sd, first):
         _, l, p, h1, r2, two, hpre, h2pre, mod = rec
@@ -549,14 +613,19 @@ class VDiffEngine:
         return g
 
     @torch.no_grad()
-    def backward(self, tape, d_v: torch.Tensor, state_dict) -> torch.Tensor:
+    def backward(self, tape, d_v: torch.Tensor, state_dict, cond_grad=None):
         """d loss / d images (NCHW fp32, images in [0, 1]) from d loss / d v (NCHW fp32 [N, 3, H, W]) and the tape of forward_train().
         `state_dict`: the model's parameters (reference key names) -- the transposed weight packings are built from it on first use.
         f16 engines scale the gradient by a power of two (largest incoming value -> 1) on the way in and back on the way out: image
-        gradients of a CLIP loss are ~1e-6 and would flush to zero in f16; bf16 needs no scaling."""
+        gradients of a CLIP loss are ~1e-6 and would flush to zero in f16; bf16 needs no scaling.
+        cond_grad = (t [N], clip_embed [N, D]) of a conditioned net: also returns d loss / d clip_embed -> (d_images, d_clip_embed)."""
         self._check_backward_support()
         dev, dt = self.device, self.dt
         n, _, hh, ww = d_v.shape
+        if cond_grad is not None:
+            if not self.cond:
+                raise ValueError("cond_grad: this net takes no conditioning")
+            self._dmod = torch.zeros((n, sum(state_dict[k].shape[0] for k in self._mod_keys)), dtype=torch.float32, device=dev)
         scale = 1.0
         if dt == _hip.DT_F16:                         # keep the f16 gradient tensors in range: largest incoming value -> 1 (power of two: exact)
             amax = float(d_v.abs().max())
@@ -568,5 +637,10 @@ class VDiffEngine:
         gx = self._back(tape, g, sd, outermost=True)                                            # fp32 [N,H,W,20]: d / d (x, Fourier planes)
         out = torch.empty((n, 3, hh, ww), dtype=torch.float32, device=dev)
         call("pmi_finish_output", ptr(gx), gx.shape[-1], ptr(out), n, hh, ww, 3)
+        if cond_grad is not None:
+            d_mod, self._dmod = self._dmod / scale, None
+            t_, ce_ = cond_grad
+            d_ce = self._mapping_back(t_.to(device=dev, dtype=torch.float32).contiguous(), ce_, d_mod.contiguous(), sd)
+            return out * (2.0 / scale), d_ce
         return out * (2.0 / scale)                                                              # x = 2 * images - 1
 

@@ -26,11 +26,15 @@ class _Velocities(torch.autograd.Function):
     def forward(ctx, diffused, t, model, clip_embed=None):
         v, tape = model.engine.forward_train(diffused, t, clip_embed)
         ctx.model, ctx.tape = model, tape
+        ctx.cond = (t, clip_embed.detach()) if (clip_embed is not None and clip_embed.requires_grad) else None
         return v
 
     @staticmethod
     def backward(ctx, grad_v):
         m = ctx.model
+        if ctx.cond is not None:            # gradient to the conditioning too (upstream: velocity_diffusion.py:96-109 keeps it in the graph)
+            gx, gce = m.engine.backward(ctx.tape, grad_v.contiguous(), m.model.state_dict(), cond_grad=ctx.cond)
+            return gx, None, None, gce
         return m.engine.backward(ctx.tape, grad_v.contiguous(), m.model.state_dict()), None, None, None
 
 
@@ -143,8 +147,8 @@ class VelocityDiffusion(torch.nn.Module):
         ce = conditioning.squeeze(dim=1) if (self.spec["cond"] and conditioning is not None) else None
         if self.spec["cond"] and ce is not None and ce.shape[0] == 1 and diffused.shape[0] > 1:
             ce = ce.expand(diffused.shape[0], -1)
-        if torch.is_grad_enabled() and diffused.requires_grad:          # autograd through the UNet (guided_resample_-style scripts)
-            return _Velocities.apply(diffused, t.to(self.device), self, ce.detach() if ce is not None else None)
+        if torch.is_grad_enabled() and (diffused.requires_grad or (ce is not None and ce.requires_grad)):   # autograd through the UNet (guided_resample_-style scripts)
+            return _Velocities.apply(diffused, t.to(self.device), self, ce.to(self.device) if ce is not None else None)
         return eng.forward(diffused, t, ce)
 
     def forward(self, diffused_images, ts, conditioning=None) -> Predictions:
