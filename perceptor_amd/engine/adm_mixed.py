@@ -30,7 +30,7 @@ import torch
 from .. import _hip
 from .._hip import ACT_SILU, DT_F16, DT_F16X2, call, ptr
 from . import ops
-from .adm import AdmConfig, AdmEngine, _Attn, _Res, _Resample, build_plan
+from .adm import AdmConfig, AdmEngine, _Attn, _Res, _Resample, build_plan  # noqa: F401
 from .ops import MixedLinear, PackedLinear
 
 # conv operands kept as ONE f16 value in the shipped GD "standard" 512x512 config (python -m oracle.error_budget --size 128 --per-conv:
@@ -115,8 +115,9 @@ class AdmMixedEngine(AdmEngine):
                     self.w[p + ".gn"] = (f32(p + ".norm.weight"), f32(p + ".norm.bias"))
                     self.w[p + ".qkv"] = plain(p + ".qkv")
                     self.w[p + ".proj"] = plain(p + ".proj_out")
-                elif isinstance(l, _Resample):
-                    raise NotImplementedError("the mixed engine covers the resblock_updown configs (the shipped 512x512 model)")
+                elif isinstance(l, _Resample) and cfg.conv_resample:       # pixelart: stride-2 / nearest-up convolutions between the levels
+                    k = l.p + (".conv" if l.up else ".op")
+                    self.w[l.p] = plain(k) if self._plain(l.ds_out) else split(k)
         self.emb_all = (torch.cat(emb_w, 0).to(dev).contiguous(), torch.cat(emb_b, 0).to(dev).contiguous())
         self.gn_out = (f32("out.0.weight"), f32("out.0.bias"))
         self.conv_out = split("out.2")
@@ -191,6 +192,17 @@ class AdmMixedEngine(AdmEngine):
                 h = self._as_plain(AdmEngine._res, l, h, h1, emb) if pout else self._res_split(l, h, h1, emb)
             elif isinstance(l, _Attn):
                 h = self._as_plain(AdmEngine._attn, l, h) if self._plain(l.ds_out) else self._attn_split(l, h)
+            elif isinstance(l, _Resample):
+                if not self.cfg.conv_resample:
+                    raise NotImplementedError("conv_resample=False is not used by the shipped configs")
+                pin, pout = self._plain(l.ds_in), self._plain(l.ds_out)
+                if pin != pout:
+                    h = ops.split_convert(h, to_split=not pout)
+                self.dt = DT_F16 if pout else DT_F16X2
+                try:          # the generic split path (doubled operand) on the split levels, the plain kernels below
+                    h = ops.igemm(h, self.w[l.p], up=l.up, stride=1 if l.up else 2, want_stats=True)
+                finally:
+                    self.dt = DT_F16X2
             h1 = None
         return h
 

@@ -40,7 +40,11 @@ class _EncodeImages(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, images, model, normalize):
-        emb = model.engine.forward(images, save=True)
+        if getattr(model, "want_features", False):      # HF-flavoured surface: the (detached) hidden state and pooled class token of this same pass
+            emb, hidden, pooled = model.engine.forward(images, save=True, features=True)
+            model.features = (hidden.detach(), pooled.detach())
+        else:
+            emb = model.engine.forward(images, save=True)
         ctx.model, ctx.normalize = model, normalize
         ctx.saved_state = model.engine.saved
         ctx.save_for_backward(emb)

@@ -42,8 +42,8 @@ class Encodings:
 class _Shim:
     """What _EncodeImages needs of a model: the engine."""
 
-    def __init__(self, engine):
-        self.engine = engine
+    def __init__(self, engine, want_features=False):
+        self.engine, self.want_features, self.features = engine, want_features, None
 
 
 class TransformersOpenAICLIP(torch.nn.Module):
@@ -145,8 +145,11 @@ class TransformersOpenAICLIP(torch.nn.Module):
         eng = self._engine("vision")
         images = images.to(self.device)
         if images.requires_grad and torch.is_grad_enabled():
-            un = _EncodeImages.apply(images, _Shim(eng), False)
-            feats = None
+            # the reference always returns features (its gradient test reads them, transformers_openai_clip.py:88-116): here they are the
+            # detached hidden state / pooled class token of the same pass; gradients flow through the encodings
+            shim = _Shim(eng, want_features=True)
+            un = _EncodeImages.apply(images, shim, False)
+            feats = SimpleNamespace(last_hidden_state=shim.features[0], pooler_output=shim.features[1])
         else:
             un, hidden, pooled = eng.forward(images, features=True)
             feats = SimpleNamespace(last_hidden_state=hidden, pooler_output=pooled)

@@ -171,3 +171,18 @@ def test_adm_standard_256_mixed_vs_precise_engine_and_routes():
     assert {r[1] for r in wd} == {"single", "dbl"} and len(wd) >= 20, (len(wd), len(trace))     # (batch 2: the 1/8 level's grids are below the tile kernels' thresholds)
     y2 = eng.forward(img, t.to(DEV)).cpu()
     assert torch.equal(y, y2)                                  # deterministic (fixed-order statistics)
+
+
+def test_adm_pixelart_64_mixed_vs_reference_golden():
+    """The other shipped config (conv_resample stride-2 / nearest-up convolutions, additive timestep conditioning, one 128-channel head):
+    no per-layer table, the by-level rule; absolute 1e-3 against the reference's output at 64x64."""
+    from perceptor_amd.engine import adm, adm_mixed
+    from perceptor_amd.utils.synth import synth_state_dict
+    g = golden("adm_pixelart_64")
+    cfg = adm.pixelart_config()
+    sd = synth_state_dict(adm.state_dict_shapes(cfg), 0)
+    eng = adm_mixed.AdmMixedEngine(cfg, sd, DEV)
+    y = eng.forward(((g["x"] + 1) / 2).to(DEV), g["t"].to(DEV))
+    err = float((y[:, :, ::4, ::4].cpu() - g["y_sub"]).abs().max())
+    print(f"[parity] adm_pixelart_64 mixed: max|err|={err:.3e} (scale {float(g['y_sub'].abs().max()):.3f})")
+    assert err < 1e-3, err

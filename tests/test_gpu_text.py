@@ -94,7 +94,11 @@ def test_transformers_openai_clip_surface_vs_clipmodel_fixture():
     assert float((d.cpu() - g["distance"]).abs().max()) < 2e-2 * float(g["distance"].abs().max())
     img = g["img"].cuda().requires_grad_(True)
     with torch.enable_grad():
-        m.spherical_distance(te, m.encode_images(img)).mean().backward()
+        ieg = m.encode_images(img)
+        m.spherical_distance(te, ieg).mean().backward()
+    # the gradient path returns features too, as upstream: the detached hidden state / pooled class token of the same pass
+    assert _rel(ieg.features.last_hidden_state.cpu(), g["image_hidden"]) < 1e-2 and _rel(ieg.features.pooler_output.cpu(), g["image_pooler"]) < 1e-2
+    assert not ieg.features.last_hidden_state.requires_grad
     cos = torch.nn.functional.cosine_similarity(img.grad.cpu().double().flatten(), g["grad"].double().flatten(), dim=0)
     assert float(cos) > 0.999 and _rel(img.grad.cpu(), g["grad"]) < 3e-2
     with pytest.raises(NotImplementedError):
