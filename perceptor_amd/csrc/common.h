@@ -21,6 +21,9 @@
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
@@ -30,6 +33,9 @@ struct F16 {
   using vec8 = f16x8;
   static __device__ __forceinline__ float to_f(u16 v) { return (float)__builtin_bit_cast(_Float16, v); }
   static __device__ __forceinline__ u16 from_f(float f) { return __builtin_bit_cast(u16, (_Float16)f); }
+  // two values -> one packed word with ONE v_cvt_pk_f16_f32 (round to nearest even, as from_f): written as two scalar conversions and an
+  // OR the compiler emits two v_cvt_pk (half of each wasted) + v_or_sdwa -- 3 issue slots per pair beside the MFMAs instead of 1
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, f16x2)); }
   static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   }
@@ -42,6 +48,7 @@ struct BF16 {
   using vec8 = bf16x8;
   static __device__ __forceinline__ float to_f(u16 v) { return __builtin_bit_cast(float, ((uint32_t)v) << 16); }
   static __device__ __forceinline__ u16 from_f(float f) { return __builtin_bit_cast(u16, (__bf16)f); }
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) { return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, bf16x2)); }
   static __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
@@ -74,10 +81,7 @@ __device__ __forceinline__ void unpack8(uint4 v, float* f) {
 }
 template <typename T>
 __device__ __forceinline__ uint4 pack8(const float* f) {
-  uint32_t w[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)T::from_f(f[2 * i]) | ((uint32_t)T::from_f(f[2 * i + 1]) << 16);
-  return make_uint4(w[0], w[1], w[2], w[3]);
+  return make_uint4(T::pack2(f[0], f[1]), T::pack2(f[2], f[3]), T::pack2(f[4], f[5]), T::pack2(f[6], f[7]));
 }
 // ---- "precise" activations (PMI_DT_F16X2) --------------------------------------------------------------------------
 // A logical tensor with C channels is stored as 2C f16 per pixel: per group of G = min(32, C) channels first the G high
@@ -127,8 +131,7 @@ __device__ __forceinline__ void store8(u16* row, int c, int C, const float* f) {
 
 template <typename T>
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
-  return make_uint2((uint32_t)T::from_f(a) | ((uint32_t)T::from_f(b) << 16),
-                    (uint32_t)T::from_f(c) | ((uint32_t)T::from_f(d) << 16));
+  return make_uint2(T::pack2(a, b), T::pack2(c, d));
 }
 
 // erf(x) by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 rounding level): one v_rcp, one v_exp and a 5-term Horner

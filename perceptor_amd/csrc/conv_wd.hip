@@ -34,6 +34,18 @@
 #ifndef WD_ILV_SIN
 #define WD_ILV_SIN 4 // the same for the split-input staging (two loads, ~115 VALU instructions per unit): same-box A/B on the mixed c5 step: 2: 61.7 ms, 3: 60.9, 4: 60.7 (bf16 with 4: +0.7 ms, hence its own value)
 #endif
+#ifndef WD_FINE
+#define WD_FINE 2
+#endif
+#ifndef WD_DIAG
+#define WD_DIAG 0    // diagnostic builds only (tools/conv_decomp.sh; results are wrong, timing is the point): 1 no weight loads in the main loop, 2 no fragment reads, 4 no patch staging, 8 no chunk barrier
+#endif
+#ifndef WD_DEFER_SIN
+#define WD_DEFER_SIN 1
+#endif
+#ifndef WD_FINE_SIN
+#define WD_FINE_SIN 2   // mixed c5 step, same box: 3: 60.8-61.0 ms, 2: 59.6, row-level hints (0): 60.3, write in front of the rows: 61.7
+#endif
 #ifndef WD_ILV
 #define WD_ILV 2     // (4 until the last sweep: 2 leaves the 128-channel tiles 12 instead of 32 B/lane of scratch and measures +2 % there) VALU instructions of the patch staging the scheduler is asked to place behind each output row's MFMAs
 #endif
@@ -79,7 +91,8 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
   constexpr int FROW = (BN / 2) * 4 + 16;              // split epilogue: fp32 image of HALF the tile's channels per pass, 16 B pad
   constexpr int EPI_BYTES = SPL ? NPX * FROW + NW * (BN / 2) * 8 + BN * 4 : NPX * SROW + NW * BN * 8 + BN * 4;
   constexpr int MAXCIN = NWN == 8 ? 2048 : 1024;       // fused-prologue coefficient table: a[Cin], b[Cin] fp32 of this image
-  constexpr int COEF_BYTES = PRO ? 2 * MAXCIN * 4 : 0;
+  constexpr int CTAB = MAXCIN + 8;                     // one coefficient table: MAXCIN channels + a unit of eight zeros (padding pixels, see read_coef)
+  constexpr int COEF_BYTES = PRO ? 2 * CTAB * 4 : 0;
   constexpr int PPIX_BYTES = NPI * NT * 4;             // source pixel of every staged piece of this thread (kept out of the registers)
   // Staging of the next patch: store slot k (k = 0..NPI-1) is group SG k; the piece it stores was loaded one slot earlier into
   // the single carried register set (piece 0 in the previous chunk's last group).  With MF16 the store slots are the half-row-0
@@ -96,6 +109,7 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
   int* const ppix_s = (int*)(smem + 2 * PATCH_BYTES + COEF_BYTES);
 
   const int tid = threadIdx.x, lane = tid & 63;
+  if (PRO && tid < 16) coef[(tid >> 3) * CTAB + MAXCIN + (tid & 7)] = 0.f;     // the zero unit of both tables (visible after the prologue's barrier)
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
   const int wn = wid;
@@ -178,40 +192,68 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
     }
     return r;
   };
-  auto read_coef = [&](int chunk, float* ga, float* gb) {
-    const float* ca = coef + chunk * LCK + sc * 8;
+  // Coefficients of one staging unit.  A padding pixel (pix < 0) reads zeros instead: its loaded values are zeros too, so act(0 * 0 + 0) = 0
+  // is the zero padding itself -- one address select per unit instead of masking the packed result (4-8 v_and beside the MFMAs).
+  // For SiLU the table holds a' = -log2(e) a, b' = -log2(e) b: u = a' x + b' = -log2(e) t feeds v_exp directly and
+  // silu(t) = t / (1 + e^-t) = u / (-(1 + 2^u) / ln 2) = u * rcp(fma(2^u, k, k)), k = -log2(e): fma, exp, fma, rcp, mul -- five vector
+  // instructions per value instead of six.  (The 128-channel tiles are vector-ISSUE bound: per 16x16x32 MFMA the SIMD has 8 spare issue
+  // cycles, MI355X_MICROARCH.md per-instruction constants, and their staging used ~105 % of them.)
+  constexpr bool PSILU = PRO == 1 + PMI_ACT_SILU;
+  constexpr float NLOG2E = -1.4426950408889634f;
+  // (split-input instantiations keep the mask: the select's extra register tipped them into in-loop scratch reloads, each a full vmcnt drain)
+  constexpr bool ZPAD = SIN == 0;
+  constexpr bool DEFER = PRO != 0 && (SIN == 0 || WD_DEFER_SIN);
+  auto read_coef = [&](int chunk, int pix, float* ga, float* gb) {
+    const float* ca = coef + ((!ZPAD || pix >= 0) ? chunk * LCK + sc * 8 : MAXCIN);
     *(float4*)ga = *(const float4*)ca; *(float4*)(ga + 4) = *(const float4*)(ca + 4);
-    *(float4*)gb = *(const float4*)(ca + MAXCIN); *(float4*)(gb + 4) = *(const float4*)(ca + MAXCIN + 4);
+    *(float4*)gb = *(const float4*)(ca + CTAB); *(float4*)(gb + 4) = *(const float4*)(ca + CTAB + 4);
   };
-  auto store_piece = [&](char* pbuf, int i, Piece pc, int pix, const float* ga, const float* gb) {
-    uint4 v = pc.v[0];
-    char* const dst = pbuf + (tid / CPR) * ROW + sc * 16 + i * (NT / CPR) * ROW;
-    if (PRO) {                                          // GroupNorm-apply + activation; zero padding stays zero
-      float f[8];
-      unpack8<T>(v, f);
-      if constexpr (SIN != 0) {
-        float lo[8];
-        unpack8<T>(pc.v[1], lo);
+  // GroupNorm-apply + activation of one staged unit (registers only), and its LDS write.  The main loop issues the two apart: the compiler
+  // cannot tell the patch buffers from each other, so every fragment read behind a write in program order waits for it -- and with the
+  // write in front of a group's MFMA rows the whole conversion had to retire before the group's second fragment read, in ONE gap between
+  // two MFMAs (~75-115 vector instructions; the interleave hints below had nothing left to place).  The write goes behind the rows.
+  auto cvt_piece = [&](Piece pc, int pix, const float* ga, const float* gb, bool mask) -> Piece {
+    if (!PRO) return pc;
+    Piece o = pc;
+    float f[8];
+    unpack8<T>(pc.v[0], f);
+    if constexpr (SIN != 0) {
+      float lo[8];
+      unpack8<T>(pc.v[1], lo);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] += lo[e];
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = act_apply(f[e] * ga[e] + gb[e], PRO - 1);
-      const uint32_t keep = pix >= 0 ? 0xffffffffu : 0u;
-      v = pack8<T>(f);
-      if constexpr (SIN == 1) {                         // second operand half: what the 16-bit value lost
-        float lo[8];
-        float hf[8];
-        unpack8<T>(v, hf);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) lo[e] = f[e] - hf[e];
-        uint4 vl = pack8<T>(lo);
-        vl.x &= keep; vl.y &= keep; vl.z &= keep; vl.w &= keep;
-        *(uint4*)(dst + CK) = vl;                       // [yh of the chunk's CK / 2 channels | their yl]: CK bytes apart
-      }
-      v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
+      for (int e = 0; e < 8; ++e) f[e] += lo[e];
     }
-    *(uint4*)dst = v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if constexpr (PSILU) {
+        const float u = __builtin_fmaf(f[e], ga[e], gb[e]);
+        f[e] = u * __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(u), NLOG2E, NLOG2E));
+      } else {
+        f[e] = act_apply(f[e] * ga[e] + gb[e], PRO - 1);
+      }
+    }
+    // mask: the prologue's first patch shares ONE coefficient read between its units, so its padding units are masked here; the main
+    // loop's units read zero coefficients instead (read_coef)
+    const uint32_t keep = (!mask || pix >= 0) ? 0xffffffffu : 0u;
+    uint4 v = pack8<T>(f);
+    if constexpr (SIN == 1) {                         // second operand half: what the 16-bit value lost
+      float lo[8];
+      float hf[8];
+      unpack8<T>(v, hf);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) lo[e] = f[e] - hf[e];
+      uint4 vl = pack8<T>(lo);
+      vl.x &= keep; vl.y &= keep; vl.z &= keep; vl.w &= keep;
+      o.v[1] = vl;
+    }
+    v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
+    o.v[0] = v;
+    return o;
+  };
+  auto write_piece = [&](char* pbuf, int i, const Piece& o) {
+    char* const dst = pbuf + (tid / CPR) * ROW + sc * 16 + i * (NT / CPR) * ROW;
+    *(uint4*)dst = o.v[0];
+    if constexpr (PRO != 0 && SIN == 1) *(uint4*)(dst + CK) = o.v[1];   // [yh of the chunk's CK / 2 channels | their yl]: CK bytes apart
   };
 
   f32x16 acc[MF16 ? 1 : 8];                             // 32x32x16: [row]
@@ -294,7 +336,7 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
 
   // ---- prologue: patch of chunk 0, the first weight groups ----
   load_wg(0, cb0 * WGC);
-  if (!MF16) load_wg(1, cb0 * WGC + 1);
+  if (!MF16 || (WD_DIAG & 1)) load_wg(1, cb0 * WGC + 1);
   {
     Piece p0[NPI];
     float ga[8], gb[8];
@@ -302,14 +344,14 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
     for (int i = 0; i < NPI; ++i) p0[i] = load_piece(cb0, ppix_s[i * NT + tid], true);    // (a thread reads only its own table entries)
     if (PRO) {
       for (int c = tid; c < CinL; c += NT) {
-        coef[c] = a.pro_a[(int64_t)img * CinL + c];
-        coef[MAXCIN + c] = a.pro_b[(int64_t)img * CinL + c];
+        coef[c] = a.pro_a[(int64_t)img * CinL + c] * (PSILU ? NLOG2E : 1.f);
+        coef[CTAB + c] = a.pro_b[(int64_t)img * CinL + c] * (PSILU ? NLOG2E : 1.f);
       }
       __syncthreads();
-      read_coef(cb0, ga, gb);
+      read_coef(cb0, 0, ga, gb);
     }
 #pragma unroll
-    for (int i = 0; i < NPI; ++i) store_piece(smem, i, p0[i], ppix_s[i * NT + tid], ga, gb);
+    for (int i = 0; i < NPI; ++i) write_piece(smem, i, cvt_piece(p0[i], ppix_s[i * NT + tid], ga, gb, true));
   }
   __syncthreads();
   STAMP(1);
@@ -355,19 +397,24 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
     const int gbase = chunk * WGC;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-      if (MF16) { if ((g & 1) == WLG) load_wg(((g >> 1) + 1 + PH) & 1, gbase + (g >> 1) + 1); }     // the next (dx, step) pair: issued in the pair's second group (WLG 1), so that the store-slot groups hold ONE weight set
+      if (WD_DIAG & 1) {}
+      else if (MF16) { if ((g & 1) == WLG) load_wg(((g >> 1) + 1 + PH) & 1, gbase + (g >> 1) + 1); }     // the next (dx, step) pair: issued in the pair's second group (WLG 1), so that the store-slot groups hold ONE weight set
       else load_wg((g + 2) % 3, gbase + g + 2);                                              // two groups ahead
-      const bool store_slot = g % SG == 0 && g / SG < NPI;            // stores piece g / SG from `pr`
+      const bool store_slot = !(WD_DIAG & 4) && g % SG == 0 && g / SG < NPI;            // stores piece g / SG from `pr`
       const int lp = (g + 1 == NG) ? 0 : (g - (SG - 1)) / SG + 1;     // piece whose load is issued in this group (if load_slot)
-      const bool load_slot = (g + 1 == NG) || (g % SG == SG - 1 && lp < NPI);
+      const bool load_slot = !(WD_DIAG & 4) && ((g + 1 == NG) || (g % SG == SG - 1 && lp < NPI));
       float ga[8], gb[8];
-      if (PRO && store_slot) read_coef(cn, ga, gb);
+      if (PRO && store_slot) read_coef(cn, pixc, ga, gb);
       Piece prn = pr;
       int pixl = pixc;
       if (load_slot) { prn = load_piece(g + 1 == NG ? cn2 : cn, pixn, g + 1 == NG ? more2 : more); pixl = pixn; }
       __builtin_amdgcn_sched_barrier(0);   // keep the global loads in front of the MFMAs (the scheduler sinks them to their use)
       // GroupNorm-apply + activation of the piece loaded a slot ago, interleaved with this group's MFMAs by the hints below
-      if (store_slot) store_piece(pn, g / SG, pr, pixc, ga, gb);
+      Piece po;
+      if (store_slot) {
+        if (PRO) po = cvt_piece(pr, pixc, ga, gb, !ZPAD);
+        if (!DEFER) write_piece(pn, g / SG, PRO ? po : pr);   // (no prologue: nothing to interleave, the registers go back at once)
+      }
       const char* const cb0 = pb + frag0 + goff(g);                                // this group's fragments
       const char* const nb = (g + 1 < NG ? pb : pn) + frag0 + goff((g + 1) % NG);  // next group's (next chunk: the other buffer)
       auto rows = [&](int i0, int i1) {
@@ -383,7 +430,8 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) acc[i] = T::mfma32(wq[g % 3][dy], xf[(i + dy + 4 * g) % 6], acc[i]);
           }
-          if (i < 4) xf[(i + 4 * g) % 6] = *(const uint4*)(cb0 + (i + 6) * PW * ROW);
+          if (WD_DIAG & 2) {}
+          else if (i < 4) xf[(i + 4 * g) % 6] = *(const uint4*)(cb0 + (i + 6) * PW * ROW);
           else if (i < 7) xf[(i + 4 * g) % 6] = *(const uint4*)(nb + (i - 4) * PW * ROW);
           else {
 #pragma unroll
@@ -392,23 +440,35 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
         }
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
+          if (WD_FINE && MF16 && PRO && store_slot && i >= (g == NG - 1 ? 1 : 2)) {
+            // staging VALU two (split input: three) at a time behind each MFMA: a 16x16x32 MFMA leaves the SIMD 8 issue cycles
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x002, SIN ? WD_FINE_SIN : WD_FINE, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          } else {
           __builtin_amdgcn_sched_group_barrier(0x008, MF16 ? 6 : 3, 0);   // the MFMAs of output row i
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);              // reload the freed fragment register
           if (PRO && store_slot && i >= 2) __builtin_amdgcn_sched_group_barrier(0x002, (SIN ? WD_ILV_SIN : WD_ILV) * 4, 0);   // staging VALU, once the coefficients are in
+          }
         }
       };
       if (g == NG - 1) {
         // the chunk's barrier: rows 0..3 of this group issue the wave's LAST reads of the current patch buffer (which the next
         // chunk's staging overwrites); rows 4..7 prefetch from the other buffer, whose staging (slots 0..NPI-1) every wave has finished
         rows(0, 4);
+        if (DEFER && store_slot) write_piece(pn, g / SG, po);      // (a store slot in the barrier group, 128-channel tiles: the write belongs in front of the barrier)
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+        if (!(WD_DIAG & 8)) __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
         rows(4, 8);
       } else {
         rows(0, 8);
       }
       __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                // rows 8, 9 were freed by the last output row as well
+      if (DEFER && store_slot && g != NG - 1) write_piece(pn, g / SG, po);
       // source pixel of the piece the NEXT load slot fetches (read now, used a group or two later)
       int pixn2 = pixn;
       if (load_slot) pixn2 = ppix_s[(((g + 1 == NG ? 0 : lp) + 1) % NPI) * NT + tid];

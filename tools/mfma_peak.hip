@@ -52,7 +52,8 @@ int main(int argc, char** argv) {
       }
       hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
-      double flops = 4.0 * (double)blocks * (threads / 64) * iters * 8 * 32768.0;
+      // per wave and iteration: 8 x one 32x32x16 (32768 flop) or 8 x four 16x16x32 (4 x 16384 flop)
+      double flops = 4.0 * (double)blocks * (threads / 64) * iters * 8 * (kind < 2 ? 32768.0 : 65536.0);
       printf("%s threads=%d blocks=%d: %.3f ms  %.1f TFLOP/s\n", names[kind], threads, blocks, ms, flops / ms / 1e9);
     }
   return 0;
