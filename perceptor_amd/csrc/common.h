@@ -70,6 +70,15 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t v
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// nontemporal forms (aux = 2) for data this kernel touches exactly once, and the matching store
+__device__ __forceinline__ uint4 buf_load16_nt(__amdgpu_buffer_rsrc_t r, uint32_t voffset, uint32_t soffset) {
+  const pmi_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voffset, soffset, 2);
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void buf_store16_nt(uint4 v, __amdgpu_buffer_rsrc_t r, uint32_t voffset, uint32_t soffset) {
+  __builtin_amdgcn_raw_buffer_store_b128((pmi_u32x4){v.x, v.y, v.z, v.w}, r, voffset, soffset, 2);
+}
+
 template <typename T>
 __device__ __forceinline__ void unpack8(uint4 v, float* f) {
   const uint32_t w[4] = {v.x, v.y, v.z, v.w};

@@ -518,23 +518,26 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
     char* const img_ = smem;
     float* const stat = (float*)(smem + NPX * FROW);     // [NW][HB][2] (sum, sumsq) partials per write-out wave, summed in a fixed order
     const int q = lane % LPR, psub = lane / LPR, cl0 = q * 8;
-    typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
     constexpr int RD = 4;                                // residual prefetch depth (iterations): 8 registers each, the accumulators are still live
+    // per-image buffer resources; lane part of an address in the vector offset, the instruction's (wave-uniform) part in the scalar offset
+    // (see the 16-bit epilogue below)
+    const int rup = a.res_up ? 1 : 0, rsz = a.res_f32 ? 4 : 2;
+    const int Hr = a.H >> rup, Wr = a.W >> rup;
+    const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(a.R ? (const char*)a.R + (int64_t)img * Hr * Wr * a.ldr * rsz : nullptr, a.R ? (int64_t)Hr * Wr * a.ldr * rsz : 0);
+    const __amdgpu_buffer_rsrc_t rs_d = make_rsrc((u16*)a.D + (int64_t)img * a.H * a.W * a.ldd, (int64_t)a.H * a.W * a.ldd * 2);
 #pragma unroll
     for (int hp = 0; hp < 2; ++hp) {
       const int nq = n0 + hp * HB + cl0;                 // this lane's 8 logical output channels (inside one 32-group)
       const int po = split_off(nq, 32);                  // their high parts inside a pixel row; low parts 32 elements further
       uint4 rh[RD], rl[RD];
+      const uint32_t rvo = (uint32_t)((psub >> rup) * a.ldr + (a.res_f32 ? nq : po)) * (uint32_t)rsz;
+      const uint32_t rlo = a.res_f32 ? 16u : 64u;        // second half: the next 4 fp32 values, or the low parts 32 elements on
+      const uint32_t dvo = (uint32_t)(psub * a.ldd + po) * 2u;
       auto load_res = [&](int t) {                       // a split residual (16 B of high + 16 B of low parts) or an fp32 one (32 B): the same bytes
-        const int p = wid * PXW + t * PPI + psub;
-        const int y = y0 + (p >> 5), x = x0 + (p & 31);
-        const int64_t rr = a.res_up ? (((int64_t)img * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.ldr
-                                    : (((int64_t)img * a.H + y) * a.W + x) * a.ldr;
-        const u32x4_* const r0 = a.res_f32 ? (const u32x4_*)((const float*)a.R + rr + nq) : (const u32x4_*)((const u16*)a.R + rr + po);
-        const u32x4_* const r1 = a.res_f32 ? r0 + 1 : (const u32x4_*)((const u16*)a.R + rr + po + 32);
-        const u32x4_ h_ = __builtin_nontemporal_load(r0);
-        const u32x4_ l_ = __builtin_nontemporal_load(r1);
-        rh[t % RD] = make_uint4(h_.x, h_.y, h_.z, h_.w); rl[t % RD] = make_uint4(l_.x, l_.y, l_.z, l_.w);
+        const int pu = wid * PXW + t * PPI;              // the instruction's first pixel (PPI = 4 / 8 divides 32: pu & 31 is even)
+        const int y = y0 + (pu >> 5), x = x0 + (pu & 31);
+        const uint32_t so = (uint32_t)(((y >> rup) * Wr + (x >> rup)) * a.ldr) * (uint32_t)rsz;
+        rh[t % RD] = buf_load16_nt(rs_r, rvo, so); rl[t % RD] = buf_load16_nt(rs_r, rvo + rlo, so);
       };
       if (a.R) {
 #pragma unroll
@@ -593,10 +596,10 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
 #pragma unroll
         for (int e = 0; e < 8; ++e) lo[e] = f[e] - hf[e];
         const uint4 vl = pack8<F16>(lo);
-        const int y = y0 + (p >> 5), x = x0 + (p & 31);
-        u16* const o = (u16*)a.D + (((int64_t)img * a.H + y) * a.W + x) * a.ldd + po;
-        __builtin_nontemporal_store((u32x4_){vh.x, vh.y, vh.z, vh.w}, (u32x4_*)o);
-        __builtin_nontemporal_store((u32x4_){vl.x, vl.y, vl.z, vl.w}, (u32x4_*)(o + 32));
+        const int pu = wid * PXW + t * PPI;
+        const uint32_t so = (uint32_t)(((y0 + (pu >> 5)) * a.W + x0 + (pu & 31)) * a.ldd) * 2u;
+        buf_store16_nt(vh, rs_d, dvo, so);
+        buf_store16_nt(vl, rs_d, dvo + 64u, so);
       }
       if (a.stats) {
 #pragma unroll
@@ -638,19 +641,23 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
   const bool col_live = n0 + cl0 < a.N;                // this lane's 8 output channels exist (Cout tail of the last tile)
   // the output is written, and the residual read, exactly once by this kernel: nontemporal hint (-0.35 % on the 512x512 step, neutral on
   // StableDiffusion's small maps; same-box A/B).  A run-time choice by output size cost registers the main loop does not have (+1.4 %).
-  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+  // Addresses: per-image buffer resources, the lane's part of the offset (its pixel inside the instruction's PPI, its 8 channels) in the
+  // vector offset and the instruction's part (row, first pixel: wave-uniform) in the SCALAR offset -- the 64-bit per-lane products of the
+  // pointer form (two v_mul_lo + v_mad_u64 per access, quarter rate) were ~2.5 of a 256-channel tile's 8.8 us of epilogue.  Dead lanes
+  // (Cout tail) and an absent residual are out-of-range offsets / an empty resource: zeros, no traffic, no branch.
+  const int rup = a.res_up ? 1 : 0;
+  const int Hr = a.H >> rup, Wr = a.W >> rup;
+  const __amdgpu_buffer_rsrc_t rs_r = make_rsrc(a.R ? (const u16*)a.R + (int64_t)img * Hr * Wr * a.ldr : nullptr,
+                                                 a.R ? ((int64_t)(Hr * Wr - 1) * a.ldr + a.N) * 2 : 0);
+  const __amdgpu_buffer_rsrc_t rs_d = make_rsrc((u16*)a.D + (int64_t)img * a.H * a.W * a.ldd, ((int64_t)(a.H * a.W - 1) * a.ldd + a.N) * 2);
+  const uint32_t rvo = col_live ? (uint32_t)((psub >> rup) * a.ldr + n0 + cl0) * 2u : PMI_BUF_OOB;
+  const uint32_t dvo = col_live ? (uint32_t)(psub * a.ldd + n0 + cl0) * 2u : PMI_BUF_OOB;
   uint4 rres[NWI];
 #pragma unroll
   for (int t = 0; t < NWI; ++t) {                      // residual loads fly while the accumulators are staged
-    const int p = wid * PXW + t * PPI + psub;
-    const int y = y0 + (p >> 5), x = x0 + (p & 31);
-    rres[t] = make_uint4(0, 0, 0, 0);
-    if (a.R && col_live) {
-      const int64_t rr = a.res_up ? (((int64_t)img * (a.H >> 1) + (y >> 1)) * (a.W >> 1) + (x >> 1)) * a.ldr
-                                  : (((int64_t)img * a.H + y) * a.W + x) * a.ldr;
-      const u32x4_ r_ = __builtin_nontemporal_load((const u32x4_*)((const u16*)a.R + rr + n0 + cl0));
-      rres[t] = make_uint4(r_.x, r_.y, r_.z, r_.w);
-    }
+    const int pu = wid * PXW + t * PPI;                // the instruction's first pixel (wave-uniform; PPI divides 32, so pu & 31 is even for PPI >= 2)
+    const int y = y0 + (pu >> 5), x = x0 + (pu & 31);
+    rres[t] = buf_load16_nt(rs_r, rvo, (uint32_t)(((y >> rup) * Wr + (x >> rup)) * a.ldr) * 2u);
   }
   // (no barrier here: the bias table is the prologue's, and the main loop's last barrier already freed the patch buffers -- what a slower
   // wave still reads from them is a prefetch past the last chunk that nothing uses)
@@ -715,8 +722,8 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
 #pragma unroll
       for (int e = 0; e < 8; ++e) { cs[e] += f[e]; cs[8 + e] += f[e] * f[e]; }
     }
-    const int y = y0 + (p >> 5), x = x0 + (p & 31);
-    if (col_live) __builtin_nontemporal_store((u32x4_){v.x, v.y, v.z, v.w}, (u32x4_*)((u16*)a.D + (((int64_t)img * a.H + y) * a.W + x) * a.ldd + n0 + cl0));
+    const int pu = wid * PXW + t * PPI;
+    buf_store16_nt(v, rs_d, dvo, (uint32_t)(((y0 + (pu >> 5)) * a.W + x0 + (pu & 31)) * a.ldd) * 2u);
   }
   STAMP(7);
   if (a.stats) {
