@@ -38,7 +38,10 @@
 #define WD_FINE 2
 #endif
 #ifndef WD_DIAG
-#define WD_DIAG 0    // diagnostic builds only (tools/conv_decomp.sh; results are wrong, timing is the point): 1 no weight loads in the main loop, 2 no fragment reads, 4 no patch staging, 8 no chunk barrier
+#define WD_DIAG 0    // diagnostic builds only (tools/conv_decomp.sh; results are wrong, timing is the point): 1 no weight loads in the main loop, 2 no fragment reads, 4 no patch staging, 8 no chunk barrier, 16 patch loads out of range (no memory latency, conversion kept)
+#endif
+#ifndef WD_EARLY
+#define WD_EARLY 0   // 1: the next piece's load issued in the store slot itself (two groups of cover instead of one, no extra registers). Measured, same box: 256 -> 256 @256x256 0.488 -> 0.511 ms, bf16 c5 39.9 -> 40.5 ms, mixed 55.5 -> 57.1 -- slower: the wait for the carried piece then opens the group, in front of every MFMA
 #endif
 #ifndef WD_DEFER_SIN
 #define WD_DEFER_SIN 1
@@ -212,10 +215,7 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
   // cannot tell the patch buffers from each other, so every fragment read behind a write in program order waits for it -- and with the
   // write in front of a group's MFMA rows the whole conversion had to retire before the group's second fragment read, in ONE gap between
   // two MFMAs (~75-115 vector instructions; the interleave hints below had nothing left to place).  The write goes behind the rows.
-  auto cvt_piece = [&](Piece pc, int pix, const float* ga, const float* gb, bool mask) -> Piece {
-    if (!PRO) return pc;
-    Piece o = pc;
-    float f[8];
+  auto unpack_piece = [&](const Piece& pc, float* f) {   // the unit's 8 values; the piece's registers are dead behind this
     unpack8<T>(pc.v[0], f);
     if constexpr (SIN != 0) {
       float lo[8];
@@ -223,6 +223,9 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] += lo[e];
     }
+  };
+  auto finish_piece = [&](float* f, int pix, const float* ga, const float* gb, bool mask) -> Piece {
+    Piece o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       if constexpr (PSILU) {
@@ -245,10 +248,18 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
       uint4 vl = pack8<T>(lo);
       vl.x &= keep; vl.y &= keep; vl.z &= keep; vl.w &= keep;
       o.v[1] = vl;
+    } else if constexpr (SIN == 2) {
+      o.v[1] = v;
     }
     v.x &= keep; v.y &= keep; v.z &= keep; v.w &= keep;
     o.v[0] = v;
     return o;
+  };
+  auto cvt_piece = [&](Piece pc, int pix, const float* ga, const float* gb, bool mask) -> Piece {
+    if (!PRO) return pc;
+    float f[8];
+    unpack_piece(pc, f);
+    return finish_piece(f, pix, ga, gb, mask);
   };
   auto write_piece = [&](char* pbuf, int i, const Piece& o) {
     char* const dst = pbuf + (tid / CPR) * ROW + sc * 16 + i * (NT / CPR) * ROW;
@@ -401,19 +412,27 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
       else if (MF16) { if ((g & 1) == WLG) load_wg(((g >> 1) + 1 + PH) & 1, gbase + (g >> 1) + 1); }     // the next (dx, step) pair: issued in the pair's second group (WLG 1), so that the store-slot groups hold ONE weight set
       else load_wg((g + 2) % 3, gbase + g + 2);                                              // two groups ahead
       const bool store_slot = !(WD_DIAG & 4) && g % SG == 0 && g / SG < NPI;            // stores piece g / SG from `pr`
-      const int lp = (g + 1 == NG) ? 0 : (g - (SG - 1)) / SG + 1;     // piece whose load is issued in this group (if load_slot)
-      const bool load_slot = !(WD_DIAG & 4) && ((g + 1 == NG) || (g % SG == SG - 1 && lp < NPI));
-      float ga[8], gb[8];
+      // EARLY (off, see WD_EARLY): the next piece's load issued in the store slot itself, as soon as the carried piece is unpacked.
+      // (Why it was tried: with the patch loads' memory latency AND traffic removed -- WD_DIAG 16 -- a 256-channel layer runs 10 % faster,
+      // 12...17 % without a prologue; vmcnt retires in order, so every wait for a weight set issued behind a piece load waits for the piece.)
+      constexpr bool EARLY = WD_EARLY && SG == 2;
+      const int lp = EARLY ? (g / SG + 1) % NPI : (g + 1 == NG) ? 0 : (g - (SG - 1)) / SG + 1;     // piece whose load is issued in this group (if load_slot)
+      const bool load_slot = !(WD_DIAG & 4) && (EARLY ? store_slot : ((g + 1 == NG) || (g % SG == SG - 1 && lp < NPI)));
+      float ga[8], gb[8], fu[8];
       if (PRO && store_slot) read_coef(cn, pixc, ga, gb);
+      if (EARLY && store_slot) {
+        if (PRO) unpack_piece(pr, fu);
+        else write_piece(pn, g / SG, pr);               // no prologue: the piece goes out as it is
+      }
       Piece prn = pr;
       int pixl = pixc;
-      if (load_slot) { prn = load_piece(g + 1 == NG ? cn2 : cn, pixn, g + 1 == NG ? more2 : more); pixl = pixn; }
+      if (load_slot) { prn = load_piece(lp == 0 ? cn2 : cn, pixn, !(WD_DIAG & 16) && (lp == 0 ? more2 : more)); pixl = pixn; }   // (piece 0 belongs to the chunk after next; diagnostic 16: the loads return zeros at once)
       __builtin_amdgcn_sched_barrier(0);   // keep the global loads in front of the MFMAs (the scheduler sinks them to their use)
       // GroupNorm-apply + activation of the piece loaded a slot ago, interleaved with this group's MFMAs by the hints below
       Piece po;
       if (store_slot) {
-        if (PRO) po = cvt_piece(pr, pixc, ga, gb, !ZPAD);
-        if (!DEFER) write_piece(pn, g / SG, PRO ? po : pr);   // (no prologue: nothing to interleave, the registers go back at once)
+        if (PRO) po = EARLY ? finish_piece(fu, pixc, ga, gb, !ZPAD) : cvt_piece(pr, pixc, ga, gb, !ZPAD);
+        if (!DEFER && !(EARLY && !PRO)) write_piece(pn, g / SG, PRO ? po : pr);   // (no prologue: nothing to interleave, the registers go back at once)
       }
       const char* const cb0 = pb + frag0 + goff(g);                                // this group's fragments
       const char* const nb = (g + 1 < NG ? pb : pn) + frag0 + goff((g + 1) % NG);  // next group's (next chunk: the other buffer)
@@ -471,7 +490,7 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
       if (DEFER && store_slot && g != NG - 1) write_piece(pn, g / SG, po);
       // source pixel of the piece the NEXT load slot fetches (read now, used a group or two later)
       int pixn2 = pixn;
-      if (load_slot) pixn2 = ppix_s[(((g + 1 == NG ? 0 : lp) + 1) % NPI) * NT + tid];
+      if (load_slot) pixn2 = ppix_s[((lp + 1) % NPI) * NT + tid];
       pr = prn; pixc = pixl; pixn = pixn2;
       __builtin_amdgcn_sched_barrier(0);
     }
