@@ -465,6 +465,7 @@ def main():
         if dist.get_world_size() != a.gpus:
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {a.gpus}")
     finite = bool(torch.isfinite(images).all().item())
+    checksum = float(images.double().abs().sum().item())     # same schedule and seed -> comparable between --graph / --chains / eager runs
 
     if rank == 0:
         step_ms_dev = sum(s.elapsed_time(e) for s, e in ev) / a.steps
@@ -533,7 +534,7 @@ def main():
                                    + (f" + OpenCLIP {clip_arch} guidance (fwd+bwd to image)" if clip_arch else " (no CLIP)")
                                    + ", DDIM eta=0, synthetic weights", "name": a.config,
                        "global_batch": nb * world, "parallelism": f"replica-sharded chains x{world}"},
-            "outputs_finite": finite,
+            "outputs_finite": finite, "images_abs_sum": round(checksum, 3),
             "rccl_ranks": dist.get_world_size() if dist is not None else 0,
             "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},     # skew between the ranks' own clocks
             **({"tape_gb": round(tape_gb, 2), "flop_note": "roofline.step counts 2x the forward FLOP (forward + dX of every layer; no weight gradients)"} if a.backward else {}),

@@ -40,6 +40,9 @@
 #ifndef WD_DIAG
 #define WD_DIAG 0    // diagnostic builds only (tools/conv_decomp.sh; results are wrong, timing is the point): 1 no weight loads in the main loop, 2 no fragment reads, 4 no patch staging, 8 no chunk barrier, 16 patch loads out of range (no memory latency, conversion kept)
 #endif
+#ifndef WD_RD
+#define WD_RD 4   // split epilogue: residual prefetch depth. 6 / 8 put 72-192 B per lane of scratch into these kernels (some of it in the main loop)
+#endif
 #ifndef WD_EARLY
 #define WD_EARLY 0   // 1: the next piece's load issued in the store slot itself (two groups of cover instead of one, no extra registers). Measured, same box: 256 -> 256 @256x256 0.488 -> 0.511 ms, bf16 c5 39.9 -> 40.5 ms, mixed 55.5 -> 57.1 -- slower: the wait for the carried piece then opens the group, in front of every MFMA
 #endif
@@ -413,8 +416,8 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
       else load_wg((g + 2) % 3, gbase + g + 2);                                              // two groups ahead
       const bool store_slot = !(WD_DIAG & 4) && g % SG == 0 && g / SG < NPI;            // stores piece g / SG from `pr`
       // EARLY (off, see WD_EARLY): the next piece's load issued in the store slot itself, as soon as the carried piece is unpacked.
-      // (Why it was tried: with the patch loads' memory latency AND traffic removed -- WD_DIAG 16 -- a 256-channel layer runs 10 % faster,
-      // 12...17 % without a prologue; vmcnt retires in order, so every wait for a weight set issued behind a piece load waits for the piece.)
+      // (Tried because WD_DIAG 16 -- patch loads that return zeros at once -- runs 10-17 % faster; but that build multiplies zeros, draws
+      // less power and clocks higher: not a latency measurement.  profiles/r03_conv_decomposition.txt.)
       constexpr bool EARLY = WD_EARLY && SG == 2;
       const int lp = EARLY ? (g / SG + 1) % NPI : (g + 1 == NG) ? 0 : (g - (SG - 1)) / SG + 1;     // piece whose load is issued in this group (if load_slot)
       const bool load_slot = !(WD_DIAG & 4) && (EARLY ? store_slot : ((g + 1 == NG) || (g % SG == SG - 1 && lp < NPI)));
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(NWN * 64, 2) void conv3x3_wd_kernel(const pmi_igemm
     char* const img_ = smem;
     float* const stat = (float*)(smem + NPX * FROW);     // [NW][HB][2] (sum, sumsq) partials per write-out wave, summed in a fixed order
     const int q = lane % LPR, psub = lane / LPR, cl0 = q * 8;
-    constexpr int RD = 4;                                // residual prefetch depth (iterations): 8 registers each, the accumulators are still live
+    constexpr int RD = WD_RD;                            // residual prefetch depth (iterations): 8 registers each, the accumulators are still live
     // per-image buffer resources; lane part of an address in the vector offset, the instruction's (wave-uniform) part in the scalar offset
     // (see the 16-bit epilogue below)
     const int rup = a.res_up ? 1 : 0, rsz = a.res_f32 ? 4 : 2;
