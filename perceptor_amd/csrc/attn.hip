@@ -258,12 +258,21 @@ __global__ __launch_bounds__(64) void vit_attn_fwd_kernel(const u16* __restrict_
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m_run = -1e30f, l_run = 0.f;
-  for (int s0 = 0; s0 < Tp; s0 += 32) {
+  struct Tile { uint4 k[4], vt[2][2]; };                 // a key tile's fragments, fetched one tile ahead (see vit_attn_dkdv_body)
+  auto load_tile = [&](int sb, Tile& f) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) f.k[kk] = *(const uint4*)(k + rfrag(bh, ntb, sb, kk, lhi, l31));
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) f.vt[ks][db] = *(const uint4*)(vt + tfrag(bh, ntb, sb, ks, db, lhi, l31));
+  };
+  auto compute = [&](const Tile& f, int s0) {
     f32x16 sacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) sacc = T_::mfma32(*(const uint4*)(k + rfrag(bh, ntb, s0 >> 5, kk, lhi, l31)), qf[kk], sacc);
+    for (int kk = 0; kk < 4; ++kk) sacc = T_::mfma32(f.k[kk], qf[kk], sacc);
     float mx = -1e30f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -286,11 +295,22 @@ __global__ __launch_bounds__(64) void vit_attn_fwd_kernel(const u16* __restrict_
 #pragma unroll
       for (int j = 0; j < 8; ++j) pf[j] = sacc[8 * ks + j];
       const uint4 pfrag = pack8<T_>(pf);
-#pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        const uint4 vf = *(const uint4*)(vt + tfrag(bh, Tp >> 5, s0 >> 5, ks, db, lhi, l31));
-        if (db == 0) o0 = T_::mfma32(vf, pfrag, o0); else o1 = T_::mfma32(vf, pfrag, o1);
-      }
+      o0 = T_::mfma32(f.vt[ks][0], pfrag, o0);
+      o1 = T_::mfma32(f.vt[ks][1], pfrag, o1);
+    }
+  };
+  Tile ta, tb_;
+  load_tile(0, ta);
+  for (int sb = 0; sb < ntb; sb += 2) {
+    load_tile(sb + 1 < ntb ? sb + 1 : sb, tb_);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(ta, sb * 32);
+    __builtin_amdgcn_sched_barrier(0);
+    if (sb + 1 < ntb) {
+      load_tile(sb + 2 < ntb ? sb + 2 : sb + 1, ta);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(tb_, (sb + 1) * 32);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   const int t = t0 + l31;
@@ -327,14 +347,27 @@ __device__ __forceinline__ void vit_attn_dq_body(const u16* __restrict__ q, cons
   f32x16 g0, g1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
-  for (int s0 = 0; s0 < Tp; s0 += 32) {
+  struct Tile { uint4 k[4], v[4], kt[2][2]; };           // a key tile's fragments, fetched one tile ahead (see the dK/dV body)
+  const int ntb = Tp >> 5;
+  auto load_tile = [&](int sb, Tile& f) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f.k[kk] = *(const uint4*)(k + rfrag(bh, ntb, sb, kk, lhi, l31));
+      f.v[kk] = *(const uint4*)(v + rfrag(bh, ntb, sb, kk, lhi, l31));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) f.kt[ks][db] = *(const uint4*)(kt + tfrag(bh, ntb, sb, ks, db, lhi, l31));
+  };
+  auto compute = [&](const Tile& f, int s0) {
     f32x16 sacc, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      sacc = T_::mfma32(*(const uint4*)(k + rfrag(bh, Tp >> 5, s0 >> 5, kk, lhi, l31)), qf[kk], sacc);
-      dp = T_::mfma32(*(const uint4*)(v + rfrag(bh, Tp >> 5, s0 >> 5, kk, lhi, l31)), dof[kk], dp);
+      sacc = T_::mfma32(f.k[kk], qf[kk], sacc);
+      dp = T_::mfma32(f.v[kk], dof[kk], dp);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -344,15 +377,26 @@ __device__ __forceinline__ void vit_attn_dq_body(const u16* __restrict__ q, cons
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      float f[8];
+      float g[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = sacc[8 * ks + j];
-      const uint4 dsf = pack8<T_>(f);
-#pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        const uint4 kf = *(const uint4*)(kt + tfrag(bh, Tp >> 5, s0 >> 5, ks, db, lhi, l31));
-        if (db == 0) g0 = T_::mfma32(kf, dsf, g0); else g1 = T_::mfma32(kf, dsf, g1);
-      }
+      for (int j = 0; j < 8; ++j) g[j] = sacc[8 * ks + j];
+      const uint4 dsf = pack8<T_>(g);
+      g0 = T_::mfma32(f.kt[ks][0], dsf, g0);
+      g1 = T_::mfma32(f.kt[ks][1], dsf, g1);
+    }
+  };
+  Tile ta, tb_;
+  load_tile(0, ta);
+  for (int sb = 0; sb < ntb; sb += 2) {
+    load_tile(sb + 1 < ntb ? sb + 1 : sb, tb_);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(ta, sb * 32);
+    __builtin_amdgcn_sched_barrier(0);
+    if (sb + 1 < ntb) {
+      load_tile(sb + 2 < ntb ? sb + 2 : sb + 1, ta);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(tb_, (sb + 1) * 32);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   const int t = t0 + l31;
@@ -387,37 +431,70 @@ __device__ __forceinline__ void vit_attn_dkdv_body(const u16* __restrict__ q, co
   f32x16 dk0, dk1, dv0, dv1;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
-  for (int t0 = 0; t0 < Tp; t0 += 32) {
+  // One wave, no LDS: every operand of a query tile comes straight from global memory in fragment order.  The tile's 16 fragment loads and
+  // its 32 lse / delta values are fetched ONE TILE AHEAD into a second register set (a 64-thread workgroup has the registers): the loop
+  // used to wait a full memory latency per tile with two or three waves per SIMD to cover it.
+  struct Tile { uint4 q[4], dO[4], dot[2][2], qt[2][2]; float ls[16], dl[16]; };
+  const int ntb = Tp >> 5;
+  auto load_tile = [&](int tb, Tile& f) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f.q[kk] = *(const uint4*)(q + rfrag(bh, ntb, tb, kk, lhi, l31));
+      f.dO[kk] = *(const uint4*)(d_o + rfrag(bh, ntb, tb, kk, lhi, l31));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const int64_t fo = tfrag(bh, ntb, tb, ks, db, lhi, l31);
+        f.dot[ks][db] = *(const uint4*)(d_ot + fo); f.qt[ks][db] = *(const uint4*)(qt + fo);
+      }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int t = tb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      f.ls[r] = lse[rb + t]; f.dl[r] = delta[rb + t];
+    }
+  };
+  auto compute = [&](const Tile& f, int t0) {
     f32x16 sacc, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      sacc = T_::mfma32(*(const uint4*)(q + rfrag(bh, Tp >> 5, t0 >> 5, kk, lhi, l31)), kf[kk], sacc);     // rows = queries, lane = key
-      dp = T_::mfma32(*(const uint4*)(d_o + rfrag(bh, Tp >> 5, t0 >> 5, kk, lhi, l31)), vf[kk], dp);
+      sacc = T_::mfma32(f.q[kk], kf[kk], sacc);     // rows = queries, lane = key
+      dp = T_::mfma32(f.dO[kk], vf[kk], dp);
     }
     float pf[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      const float p = (key_ok && t < T) ? __expf(sacc[r] * scale - lse[rb + t]) : 0.f;
+      const float p = (key_ok && t < T) ? __expf(sacc[r] * scale - f.ls[r]) : 0.f;
       pf[r] = p;
-      sacc[r] = p * (dp[r] - delta[rb + t]) * scale;            // dS[t][s]
+      sacc[r] = p * (dp[r] - f.dl[r]) * scale;            // dS[t][s]
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const uint4 pfrag = pack8<T_>(pf + 8 * ks);
-      float f[8];
+      float g[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = sacc[8 * ks + j];
-      const uint4 dsf = pack8<T_>(f);
-#pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        const int64_t fo = tfrag(bh, Tp >> 5, t0 >> 5, ks, db, lhi, l31);
-        const uint4 dof = *(const uint4*)(d_ot + fo), qf = *(const uint4*)(qt + fo);
-        if (db == 0) { dv0 = T_::mfma32(dof, pfrag, dv0); dk0 = T_::mfma32(qf, dsf, dk0); }
-        else { dv1 = T_::mfma32(dof, pfrag, dv1); dk1 = T_::mfma32(qf, dsf, dk1); }
-      }
+      for (int j = 0; j < 8; ++j) g[j] = sacc[8 * ks + j];
+      const uint4 dsf = pack8<T_>(g);
+      dv0 = T_::mfma32(f.dot[ks][0], pfrag, dv0); dk0 = T_::mfma32(f.qt[ks][0], dsf, dk0);
+      dv1 = T_::mfma32(f.dot[ks][1], pfrag, dv1); dk1 = T_::mfma32(f.qt[ks][1], dsf, dk1);
+    }
+  };
+  Tile ta, tb_;
+  load_tile(0, ta);
+  for (int tb = 0; tb < ntb; tb += 2) {                  // two tiles per trip: the register sets swap roles without copies
+    load_tile(tb + 1 < ntb ? tb + 1 : tb, tb_);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(ta, tb * 32);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tb + 1 < ntb) {
+      load_tile(tb + 2 < ntb ? tb + 2 : tb + 1, ta);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(tb_, (tb + 1) * 32);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   const int s = s0 + l31;
