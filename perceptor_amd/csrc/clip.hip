@@ -101,6 +101,35 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 // ---- LayerNorm fused with the split-K reduction of the GEMM in front of it (ViT, M = 2056: the reduce pass and the LayerNorm pass were two
 // launch-bound kernels over the same 8 MB).  x[row] = sum_s ws[s][row] + bias + residual[row]; one wave per row, the row stays in registers.
+// a[k] = sum over the split-K slabs of this lane's k-th float4 of a row, in slab order (fixed: deterministic, and the same order as a
+// serial loop).  All loads of up to four slabs are issued before the first add: the serial form (one load, one add, per value and slab)
+// paid nslab x nv dependent L2 latencies per row -- 16 of them for a 1024-wide row in four slabs, most of these kernels' 15 us.
+__device__ __forceinline__ void sum_slabs(const float* __restrict__ ws, int nslab, int64_t slab_stride, int64_t rowoff, int lane, int nv, float4* a) {
+  float4 p[3][8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (k < nv) a[k] = *(const float4*)(ws + rowoff + (lane + 64 * k) * 4);
+#pragma unroll
+  for (int z = 1; z < 4; ++z)
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < nv && z < nslab) p[z - 1][k] = *(const float4*)(ws + z * slab_stride + rowoff + (lane + 64 * k) * 4);
+#pragma unroll
+  for (int z = 1; z < 4; ++z)
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < nv && z < nslab) { a[k].x += p[z - 1][k].x; a[k].y += p[z - 1][k].y; a[k].z += p[z - 1][k].z; a[k].w += p[z - 1][k].w; }
+  for (int z = 4; z < nslab; ++z) {
+    float4 q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < nv) q[k] = *(const float4*)(ws + z * slab_stride + rowoff + (lane + 64 * k) * 4);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k < nv) { a[k].x += q[k].x; a[k].y += q[k].y; a[k].z += q[k].z; a[k].w += q[k].w; }
+  }
+}
+
 // forward: writes x (the residual stream) and LayerNorm(x) as 16-bit GEMM operand (+ mean / rstd);  D % 256 == 0, D <= 2048.
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_fwd_slabs_kernel(const float* __restrict__ ws, int nslab, int64_t slab_stride,
@@ -113,15 +142,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_slabs_kernel(const float* _
   const int nv = D >> 8;
   float4 v[8];
   float s = 0.f;
+  sum_slabs(ws, nslab, slab_stride, (int64_t)row * D, lane, nv, v);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     if (k < nv) {
       const int c = (lane + 64 * k) * 4;
-      float4 a = *(const float4*)(ws + (int64_t)row * D + c);
-      for (int z = 1; z < nslab; ++z) {                       // fixed order: deterministic
-        const float4 p = *(const float4*)(ws + z * slab_stride + (int64_t)row * D + c);
-        a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
-      }
+      float4 a = v[k];
       if (bias) { const float4 b = *(const float4*)(bias + c); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
       if (res) { const float4 r = *(const float4*)(res + (int64_t)row * D + c); a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
       *(float4*)(xo + (int64_t)row * D + c) = a;
@@ -164,15 +190,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_slabs_kernel(const float* _
   const int nv = D >> 8;
   float4 gy[8], xh[8];
   float s1 = 0.f, s2 = 0.f;
+  sum_slabs(ws, nslab, slab_stride, (int64_t)r * D, lane, nv, gy);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     if (k < nv) {
       const int c = (lane + 64 * k) * 4;
-      float4 d = *(const float4*)(ws + (int64_t)r * D + c);
-      for (int z = 1; z < nslab; ++z) {
-        const float4 p = *(const float4*)(ws + z * slab_stride + (int64_t)r * D + c);
-        d.x += p.x; d.y += p.y; d.z += p.z; d.w += p.w;
-      }
+      const float4 d = gy[k];
       const float4 g = *(const float4*)(gamma + c), xv = *(const float4*)(x + (int64_t)r * D + c);
       gy[k] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
       xh[k] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
