@@ -245,6 +245,17 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_wd_kernel(const pmi_igemm_ar
     __syncthreads();
     const bool d2_img = a.D2 && a.act != PMI_ACT_NONE;   // without an activation the second output equals the first
     const int pc8 = tid % (BN / 8), prow = tid / (BN / 8);     // 8 columns (16 B) x rows prow + 16 j
+    // residual / activation-gradient operand of all MB rows of this thread, loaded up front: read inside the loop below they sit behind the
+    // previous row's store (the compiler must assume the tensors alias), one exposed memory latency per row
+    uint4 rv[MB], av[MB];
+#pragma unroll
+    for (int j = 0; j < MB; ++j) {
+      const int m = m0 + prow + 16 * j;
+      const bool live = m < a.M && n0 + pc8 * 8 < a.N;
+      rv[j] = av[j] = make_uint4(0, 0, 0, 0);
+      if (live && a.aux) av[j] = *(const uint4*)((const u16*)a.aux + (int64_t)m * a.ldd + n0 + pc8 * 8);
+      if (live && a.R) rv[j] = *(const uint4*)((const u16*)a.R + (int64_t)m * a.ldr + n0 + pc8 * 8);
+    }
 #pragma unroll
     for (int j = 0; j < MB; ++j) {
       const int r = prow + 16 * j, m = m0 + r;
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_wd_kernel(const pmi_igemm_ar
         float f[8], rr[8];
         unpack8<T>(v, f);
         if (a.aux) {
-          unpack8<T>(*(const uint4*)((const u16*)a.aux + (int64_t)m * a.ldd + n0 + pc8 * 8), rr);
+          unpack8<T>(av[j], rr);
           switch (a.aux_act) {                            // the activation code is folded per case (no per-value switch)
             case PMI_ACT_GELU:
 #pragma unroll
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(NWV * 64, 2) void gemm_wd_kernel(const pmi_igemm_ar
           }
         }
         if (a.R) {
-          unpack8<T>(*(const uint4*)((const u16*)a.R + (int64_t)m * a.ldr + n0 + pc8 * 8), rr);
+          unpack8<T>(rv[j], rr);
 #pragma unroll
           for (int e = 0; e < 8; ++e) f[e] += rr[e];
         }
